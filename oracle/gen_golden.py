@@ -1,0 +1,282 @@
+"""TEST INFRASTRUCTURE — generates tests/golden/* from the imported reference.
+
+Run in the BUILD CONTAINER ONLY (needs /root/reference):
+
+    python oracle/gen_golden.py
+
+Every number written here is produced by the reference's own, unmodified code
+(``PluginLoader.get_classifier('i3d_ori')`` and the layer modules under
+altfreezing/slowfast/models), fed with seeded synthetic weights/inputs from the
+product's ``synth`` recipe.  Only data (inputs' seeds + hashes, expected outputs)
+is committed; no reference source travels.
+
+Fixtures
+  layout.json       the reference's ``network.state_dict()`` keys / shapes / dtypes
+  f1_logits.json    full-size logits, fp32 and fp64, W(seed=0), three seeded clips
+  f2_stages.npz     per-stage statistics + sampled activations for clip 0
+  f3_kats.npz/.json per-layer-class known-answer tests on small tensors
+  f4_load.json      behaviour table of ``ModelBase.load`` on crafted checkpoints
+"""
+import json
+import os
+import sys
+import tempfile
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import af_mi355x  # noqa: E402  (alias of the product package; only its synth/arch data recipes are used)
+from af_mi355x import arch, synth  # noqa: E402
+import ref_import  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+WEIGHT_SEED = 0
+CLIP_SEED = 2026
+
+
+def _layout_of(module):
+    return [(k, list(v.shape), str(v.dtype).replace("torch.", "")) for k, v in module.state_dict().items()]
+
+
+def gen_layout(clf):
+    lay = _layout_of(clf.network)
+    with open(os.path.join(GOLD, "layout.json"), "w") as f:
+        json.dump({"source": "reference PluginLoader.get_classifier('i3d_ori')().network.state_dict()",
+                   "num_keys": len(lay),
+                   "num_params": int(sum(p.numel() for p in clf.network.parameters())),
+                   "entries": lay}, f)
+    mine = [(k, list(s), d) for k, s, d in arch.state_dict_layout(arch.i3d_r50_spec())]
+    assert mine == lay, "product architecture table disagrees with the reference state_dict layout"
+    print("layout: %d keys, matches arch.state_dict_layout" % len(lay))
+
+
+def _sample_idx(numel, n=64, seed=7):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randint(0, numel, (n,), generator=g)
+
+
+def gen_f1_f2(clf):
+    sd = synth.synthetic_state_dict(seed=WEIGHT_SEED)
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "w0.pth")
+        torch.save(sd, path)
+        ok, epoch = clf.load(path)            # the reference's own loader
+        assert ok and epoch == -1
+    got = clf.network.state_dict()
+    assert all(torch.equal(got[k], sd[k]) for k in sd)
+
+    clips = [("uniform", CLIP_SEED, 0), ("uniform", CLIP_SEED, 1), ("smooth", CLIP_SEED, 0)]
+    entries = []
+    stage_out = {}
+    hooks = []
+    res = clf.network.resnet
+    for name, mod in (("s1", res.s1), ("s2", res.s2), ("pool", res.pathway0_pool), ("s3", res.s3),
+                      ("s4", res.s4), ("s5", res.s5), ("avgpool", res.head.pathway0_avgpool)):
+        def mk(n):
+            def hook(m, inp, out):
+                o = out[0] if isinstance(out, (list, tuple)) else out
+                stage_out[n] = o.detach().clone()
+            return hook
+        hooks.append(mod.register_forward_hook(mk(name)))
+
+    f2 = {}
+    for ci, (kind, seed, index) in enumerate(clips):
+        u8 = synth.synthetic_clips_u8(index + 1, seed=seed, kind=kind)[index:index + 1]
+        x = synth.normalize_like_callers(u8)
+        assert x.is_contiguous(memory_format=torch.channels_last_3d)
+        with torch.no_grad():
+            y32 = clf(x)["final_output"]
+        if ci == 0:
+            for n, t in stage_out.items():
+                flat = t.flatten()
+                idx = _sample_idx(flat.numel())
+                f2[n + "_shape"] = np.array(t.shape, dtype=np.int64)
+                f2[n + "_stats"] = np.array([flat.double().mean().item(), flat.double().abs().mean().item(),
+                                             flat.max().item(), flat.min().item()], dtype=np.float64)
+                f2[n + "_idx"] = idx.numpy()
+                f2[n + "_val"] = flat[idx].numpy()
+        clf64 = clf.double()
+        with torch.no_grad():
+            y64 = clf64(x.double())["final_output"]
+        clf.float()
+        entries.append({"kind": kind, "seed": seed, "index": index, "clip_sha256": synth.tensor_sha256(u8),
+                        "logit_f32": float(y32[0, 0]), "logit_f32_hex": y32[0, 0].item().hex(),
+                        "logit_f64": float(y64[0, 0])})
+        print("F1 clip", kind, index, "logit f32 %.9g f64 %.12g" % (y32[0, 0].item(), y64[0, 0].item()))
+    # batch invariance of the reference (B=2 equals two B=1 runs)
+    u8 = synth.synthetic_clips_u8(2, seed=CLIP_SEED, kind="uniform")
+    with torch.no_grad():
+        yb = clf(synth.normalize_like_callers(u8))["final_output"]
+    batch2 = [float(yb[0, 0]), float(yb[1, 0])]
+    for h in hooks:
+        h.remove()
+    with open(os.path.join(GOLD, "f1_logits.json"), "w") as f:
+        json.dump({"source": "reference i3d_ori forward, PyTorch CPU, weights W(seed) loaded via ModelBase.load",
+                   "torch": torch.__version__, "weights_seed": WEIGHT_SEED,
+                   "weights_sha256": synth.state_dict_sha256(sd), "clips": entries,
+                   "batch2_uniform_logits_f32": batch2}, f, indent=1)
+    np.savez_compressed(os.path.join(GOLD, "f2_stages.npz"), **f2)
+
+
+def _fill(module, seed, prefix, final_bn=(), linear=()):
+    lay = [(prefix + k, s, d) for k, s, d in _layout_of(module)]
+    sd = synth.fill_layout(lay, seed, final_bn=[prefix + b for b in final_bn], linear=[prefix + l for l in linear])
+    module.load_state_dict({k[len(prefix):]: v for k, v in sd.items()})
+    return lay
+
+
+def gen_f3():
+    ref = ref_import.reference_modules()
+    RB = ref.resnet_helper.ResBlock
+    BT = ref.resnet_helper.BottleneckTransform
+    cases = []
+    arrays = {}
+
+    def run(name, module, in_shape, seed, meta, final_bn=(), linear=(), scale=1.0):
+        module.eval()
+        lay = _fill(module, seed, name + ".", final_bn, linear)
+        x = synth.synthetic_tensor(in_shape, seed, scale)
+        with torch.no_grad():
+            y = module(x.clone())
+        arrays[name + "_out"] = y.numpy()
+        meta = dict(meta)
+        meta.update({"name": name, "seed": seed, "in_shape": list(in_shape), "in_scale": scale,
+                     "in_sha256": synth.tensor_sha256(x), "layout": lay,
+                     "final_bn": list(final_bn), "linear": list(linear), "out_shape": list(y.shape)})
+        cases.append(meta)
+        print("F3", name, tuple(in_shape), "->", tuple(y.shape))
+
+    run("stem", ref.stem_helper.ResNetBasicStem(3, 64, [5, 7, 7], [1, 2, 2], [2, 3, 3]),
+        (1, 3, 6, 40, 40), 11, {"kind": "stem"})
+    run("stem_b2", ref.stem_helper.ResNetBasicStem(3, 64, [5, 7, 7], [1, 2, 2], [2, 3, 3]),
+        (2, 3, 5, 34, 38), 12, {"kind": "stem"})
+    run("block_proj_s1", RB(64, 256, 3, 1, BT, 64), (1, 64, 4, 10, 10), 21,
+        {"kind": "block", "stride": 1}, final_bn=["branch2.c_bn"])
+    run("block_proj_s2", RB(256, 512, 3, 2, BT, 128), (1, 256, 3, 8, 8), 22,
+        {"kind": "block", "stride": 2}, final_bn=["branch2.c_bn"])
+    run("block_proj_s2_odd", RB(256, 512, 1, 2, BT, 128), (2, 256, 2, 7, 9), 23,
+        {"kind": "block", "stride": 2}, final_bn=["branch2.c_bn"])
+    run("block_id_t1", RB(256, 256, 1, 1, BT, 64), (1, 256, 3, 6, 6), 24,
+        {"kind": "block", "stride": 1}, final_bn=["branch2.c_bn"])
+    run("block_id_t3", RB(256, 256, 3, 1, BT, 64), (2, 256, 5, 5, 7), 25,
+        {"kind": "block", "stride": 1}, final_bn=["branch2.c_bn"])
+    run("pool_t2", torch.nn.MaxPool3d(kernel_size=[2, 1, 1], stride=[2, 1, 1], padding=[0, 0, 0]),
+        (2, 64, 6, 5, 5), 31, {"kind": "maxpool", "kernel": [2, 1, 1], "stride": [2, 1, 1], "pad": [0, 0, 0]})
+    run("pool_t2_odd", torch.nn.MaxPool3d(kernel_size=[2, 1, 1], stride=[2, 1, 1], padding=[0, 0, 0]),
+        (1, 64, 7, 3, 4), 32, {"kind": "maxpool", "kernel": [2, 1, 1], "stride": [2, 1, 1], "pad": [0, 0, 0]})
+    run("pool_s133", torch.nn.MaxPool3d(kernel_size=[1, 3, 3], stride=[1, 2, 2], padding=[0, 1, 1]),
+        (1, 64, 2, 9, 12), 33, {"kind": "maxpool", "kernel": [1, 3, 3], "stride": [1, 2, 2], "pad": [0, 1, 1]})
+
+    class _Head(torch.nn.Module):                       # ResNetBasicHead takes a 1-list
+        def __init__(self, h):
+            super().__init__()
+            self.h = h
+
+        def forward(self, x):
+            return self.h([x])
+
+        def state_dict(self, *a, **k):
+            return self.h.state_dict(*a, **k)
+
+        def load_state_dict(self, sd, *a, **k):
+            return self.h.load_state_dict(sd, *a, **k)
+
+    run("head", _Head(ref.head_helper.ResNetBasicHead([128], 1, [[2, 3, 3]], dropout_rate=0.5)),
+        (2, 128, 2, 3, 3), 41, {"kind": "head", "pool": [2, 3, 3]}, linear=["projection"])
+    run("head_multi", _Head(ref.head_helper.ResNetBasicHead([128], 1, [[2, 3, 3]], dropout_rate=0.5)),
+        (1, 128, 3, 3, 4), 42, {"kind": "head", "pool": [2, 3, 3]}, linear=["projection"])
+
+    class _Fuse(torch.nn.Module):                       # FuseFastToSlow takes [slow, fast]
+        def __init__(self, f):
+            super().__init__()
+            self.f = f
+
+        def forward(self, x):
+            xs, xf = x[:, :16, ::4], x                   # any slow tensor; fusion only reads fast
+            return self.f([xs, xf])[0][:, 16:]
+
+        def state_dict(self, *a, **k):
+            return self.f.state_dict(*a, **k)
+
+        def load_state_dict(self, sd, *a, **k):
+            return self.f.load_state_dict(sd, *a, **k)
+
+    run("fuse_f2s", _Fuse(ref.video_model_builder.FuseFastToSlow(64, 2, 5, 4)),
+        (1, 64, 16, 6, 6), 51, {"kind": "fuse", "ratio": 2, "kernel": 5, "alpha": 4})
+
+    np.savez_compressed(os.path.join(GOLD, "f3_kats.npz"), **arrays)
+    with open(os.path.join(GOLD, "f3_kats.json"), "w") as f:
+        json.dump({"source": "reference layer modules (stem_helper/resnet_helper/head_helper/"
+                             "video_model_builder.FuseFastToSlow), eval mode, PyTorch CPU fp32",
+                   "cases": cases}, f)
+
+
+def gen_f4(clf):
+    """ModelBase.load behaviour table (altfreezing/model/_base.py:39-104)."""
+    base = synth.synthetic_state_dict(seed=3)
+    probe = "resnet.head.projection.bias"
+    other = "resnet.s1.pathway0_stem.bn.bias"
+    rows = []
+    with tempfile.TemporaryDirectory() as td:
+        def case(name, obj=None, raw_bytes=None, path=None):
+            clf.load_state_dict({k: torch.zeros_like(v) for k, v in clf.state_dict().items()})
+            p = path or os.path.join(td, name + ".pth")
+            if obj is not None:
+                torch.save(obj, p)
+            elif raw_bytes is not None:
+                with open(p, "wb") as f:
+                    f.write(raw_bytes)
+            try:
+                ret = clf.load(p)
+                err = None
+            except Exception as e:                       # noqa: BLE001
+                ret, err = None, type(e).__name__
+            cur = clf.network.state_dict()
+            rows.append({"case": name, "ret": list(ret) if ret is not None else None, "raises": err,
+                         "probe_loaded": bool(torch.equal(cur[probe], base[probe])),
+                         "other_loaded": bool(torch.equal(cur[other], base[other]))})
+            print("F4", rows[-1])
+
+        case("raw", obj=base)
+        case("wrap_state_dict", obj={"state_dict": base, "epoch": 7})
+        case("wrap_classifier_state_dict", obj={"classifier_state_dict": base})
+        case("wrap_model_state_dict", obj={"model_state_dict": base})
+        for pfx in ("module.", "network.", "_warped_network."):
+            case("prefix_" + pfx.strip("._"), obj={pfx + k: v for k, v in base.items()})
+        case("prefix_double", obj={"module.network." + k: v for k, v in base.items()})
+        case("extra_key", obj=dict(base, **{"resnet.extra.weight": torch.ones(3)}))
+        missing = {k: v for k, v in base.items() if k != probe}
+        case("missing_probe", obj=missing)
+        bad = dict(base)
+        bad[probe] = torch.ones(5)
+        case("shape_mismatch_probe", obj=bad)
+        case("missing_file", path=os.path.join(td, "does_not_exist.pth"))
+        case("epoch_arg_passthrough", obj=base)
+        clf.load_state_dict({k: torch.zeros_like(v) for k, v in clf.state_dict().items()})
+        p = os.path.join(td, "e.pth")
+        torch.save(base, p)
+        rows.append({"case": "epoch_kw", "ret": list(clf.load(p, epoch=12))})
+    with open(os.path.join(GOLD, "f4_load.json"), "w") as f:
+        json.dump({"source": "reference ModelBase.load on crafted checkpoints (weights W(seed=3)); "
+                             "probe = resnet.head.projection.bias, other = resnet.s1.pathway0_stem.bn.bias",
+                   "rows": rows}, f, indent=1)
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    clf = ref_import.build_reference_classifier()
+    gen_layout(clf)
+    gen_f3()
+    gen_f4(clf)
+    gen_f1_f2(clf)
+
+
+if __name__ == "__main__":
+    main()

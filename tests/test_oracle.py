@@ -1,0 +1,104 @@
+"""CPU: the oracle restatement (oracle/i3d_oracle.py) against the golden vectors that
+oracle/gen_golden.py produced from the imported reference."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_json, load_npz
+
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import i3d_oracle as oracle  # noqa: E402
+from af_mi355x import arch, synth  # noqa: E402
+
+
+def test_layout_matches_reference():
+    lay = load_json("layout.json")
+    mine = [[k, list(s), d] for k, s, d in arch.state_dict_layout(arch.i3d_r50_spec())]
+    assert lay["num_keys"] == 320 and lay["num_params"] == 27225921
+    assert mine == lay["entries"]
+
+
+def test_macs_match_survey():
+    total, rows = arch.conv_macs_per_clip(arch.i3d_r50_spec())
+    assert total == 113627365376 and len(rows) == 53
+
+
+def _kat_state(case):
+    name = case["name"]
+    return synth.fill_layout([tuple(e) for e in case["layout"]], case["seed"],
+                             final_bn=[name + "." + b for b in case["final_bn"]],
+                             linear=[name + "." + l for l in case["linear"]])
+
+
+def _kat_input(case):
+    x = synth.synthetic_tensor(case["in_shape"], case["seed"], case["in_scale"])
+    assert synth.tensor_sha256(x) == case["in_sha256"]
+    return x
+
+
+def run_oracle_kat(case):
+    sd, x, name = _kat_state(case), _kat_input(case), case["name"]
+    kind = case["kind"]
+    with torch.no_grad():
+        if kind == "stem":
+            return oracle.stem(x, sd, name)
+        if kind == "block":
+            return oracle.res_block(x, sd, name, case["stride"])
+        if kind == "maxpool":
+            return torch.nn.functional.max_pool3d(x, case["kernel"], case["stride"], case["pad"])
+        if kind == "head":
+            return oracle.head(x, sd, tuple(case["pool"]), name)
+        if kind == "fuse":
+            k, a = case["kernel"], case["alpha"]
+            return oracle.conv_bn_act(x, sd[name + ".conv_f2s.weight"], sd, name + ".bn", (a, 1, 1), (k // 2, 0, 0), True)
+    raise KeyError(kind)
+
+
+def test_kats_bit_exact(golden_f3):
+    cases, arrays = golden_f3
+    assert len(cases) >= 13
+    for case in cases:
+        got = run_oracle_kat(case).numpy()
+        want = arrays[case["name"] + "_out"]
+        assert got.shape == want.shape, case["name"]
+        if case["kind"] == "head":      # torch.cat in the reference changes the GEMV's memory layout: last-bit noise
+            np.testing.assert_allclose(got, want, rtol=0, atol=1e-6, err_msg=case["name"])
+        else:
+            assert np.array_equal(got, want), "%s: max|d|=%g" % (case["name"], np.abs(got - want).max())
+
+
+def test_full_size_logits_and_stages(golden_f1, weights0):
+    f2 = load_npz("f2_stages.npz")
+    for ci, c in enumerate(golden_f1["clips"]):
+        u8 = synth.synthetic_clips_u8(c["index"] + 1, seed=c["seed"], kind=c["kind"])[c["index"]:c["index"] + 1]
+        assert synth.tensor_sha256(u8) == c["clip_sha256"]
+        x = oracle.normalize(u8)
+        assert torch.equal(x, synth.normalize_like_callers(u8))
+        logits, stages = oracle.forward(weights0, x, return_stages=True)
+        assert logits.shape == (1, 1)
+        assert abs(float(logits[0, 0]) - c["logit_f32"]) <= 1e-5
+        assert abs(float(logits[0, 0]) - c["logit_f64"]) <= 1e-4
+        if ci == 0:
+            for n, t in stages.items():
+                assert list(t.shape) == list(f2[n + "_shape"]), n
+                flat = t.flatten()
+                np.testing.assert_allclose(flat[torch.from_numpy(f2[n + "_idx"])].numpy(), f2[n + "_val"],
+                                           rtol=1e-4, atol=1e-5, err_msg=n)
+                np.testing.assert_allclose(float(flat.double().abs().mean()), f2[n + "_stats"][1], rtol=1e-5)
+
+
+def test_checkpoint_unwrap_rules():
+    base = {"resnet.a": torch.ones(1)}
+    assert list(oracle.strip_checkpoint({"state_dict": {"module.resnet.a": 1}})) == ["resnet.a"]
+    assert list(oracle.strip_checkpoint({"module.network.resnet.a": 1})) == ["network.resnet.a"]
+    assert list(oracle.strip_checkpoint(base)) == ["resnet.a"]
+
+
+def test_scores_postprocessing():
+    l = torch.tensor([[0.0], [2.0]])
+    assert torch.allclose(oracle.scores(l), torch.sigmoid(l[:, 0]))
+    l2 = torch.tensor([[0.0, 1.0]])
+    assert torch.allclose(oracle.scores(l2), torch.softmax(l2, 1)[:, 1])
