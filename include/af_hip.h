@@ -1,0 +1,161 @@
+/*
+ * af_hip.h — C ABI of libafhip.so: the MI355X (gfx950) kernels behind the AltFreezing
+ * `i3d_ori` clip classifier forward.
+ *
+ * The reference has no FFI: its hot path is stock torch.nn modules called from Python
+ * (SURVEY.md section 8b).  Each entry point below therefore names the reference *operator
+ * sequence* it replaces (file:line under /root/reference/altfreezing unless noted); the
+ * ctypes binding a maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain pointers and ints only; every buffer is caller-owned DEVICE memory (16-byte
+ *     aligned) and must stay alive until the stream has drained;
+ *   - activations are NDHWC (channels innermost), element type `dtype` (AF_F32/AF_BF16/AF_F16);
+ *     accumulation is always fp32; BatchNorm is applied as a per-channel fp32 scale/shift
+ *     in the producing kernel's epilogue;
+ *   - kernels are enqueued asynchronously on `stream` (a hipStream_t passed as void*,
+ *     NULL = the null stream); nothing here synchronises, allocates or frees device memory,
+ *     except the *_timed entry points which record and wait for their own events;
+ *   - return value 0 = success, negative = error; af_last_error() (thread-local text).
+ */
+#ifndef AF_HIP_H
+#define AF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AF_ABI_VERSION 1
+
+enum af_dtype { AF_F32 = 0, AF_BF16 = 1, AF_F16 = 2 };
+
+enum af_status {
+    AF_OK = 0,
+    AF_ERR_ARG = -1,        /* bad pointer / dimension / unsupported configuration */
+    AF_ERR_LAUNCH = -2,     /* hipLaunch / runtime error */
+    AF_ERR_NO_DEVICE = -3
+};
+
+/* stem input geometry: [N][T+4][H+6][W+8][4] with zero halos (2 | 3 | 3-left,5-right) and a
+ * zero 4th channel; written by af_pack_input_* and read by af_stem_conv_bn_relu. */
+#define AF_STEM_PAD_T 2
+#define AF_STEM_PAD_H 3
+#define AF_STEM_PAD_W_LEFT 3
+#define AF_STEM_PAD_W_TOTAL 8
+#define AF_STEM_CPAD 4
+
+typedef struct af_conv_desc {
+    int32_t n, t, h, w, cin;        /* input  [n][t][h][w][cin]              */
+    int32_t cout;
+    int32_t kt, kh, kw;
+    int32_t st, sh, sw;
+    int32_t pt, ph, pw;
+    int32_t to, ho, wo;             /* output [n][to][ho][wo][cout]; checked */
+    int32_t relu;                   /* ReLU after scale/shift(+residual)     */
+    int32_t dtype;                  /* af_dtype of in / weights / residual / out */
+} af_conv_desc;
+
+typedef struct af_pool_desc {
+    int32_t n, t, h, w, c;
+    int32_t kt, kh, kw, st, sh, sw, pt, ph, pw;
+    int32_t to, ho, wo;
+    int32_t dtype;
+} af_pool_desc;
+
+int af_version(void);
+const char* af_last_error(void);
+/* number of visible HIP devices, or AF_ERR_NO_DEVICE */
+int af_device_count(void);
+
+/* ---- one-time weight transforms (model load) ------------------------------------------- */
+
+/* nn.BatchNorm3d(eval) -> scale = gamma / sqrt(var + eps), shift = beta - mean * scale
+ * (slowfast/models/batchnorm_helper.py:23-24; applied at stem_helper.py:175, resnet_helper.py:314-325,441) */
+int af_fold_bn(const float* gamma, const float* beta, const float* mean, const float* var,
+               float eps, int channels, float* scale, float* shift, void* stream);
+
+/* nn.Conv3d weight OIDHW fp32 -> [cout][kt*kh*kw][cin] in `dtype` (K-major rows for the
+ * implicit GEMM).  Output bytes: af_packed_conv_weight_bytes(). */
+int64_t af_packed_conv_weight_bytes(int cout, int cin, int kt, int kh, int kw, int dtype);
+int af_pack_conv_weight(const float* w_oidhw, int cout, int cin, int kt, int kh, int kw,
+                        int dtype, void* packed, void* stream);
+
+/* stem weight (64,3,kt,7,7) fp32 -> [kt][7][chunk][64][16 B]: kw padded 7->8, cin 3->4 (zeros) */
+int64_t af_packed_stem_weight_bytes(int cout, int kt, int kh, int dtype);
+int af_pack_stem_weight(const float* w_oidhw, int cout, int kt, int kh, int kw, int dtype,
+                        void* packed, void* stream);
+
+/* ---- input prologue (replaces the callers' as_tensor/permute/sub/div, test/af_realtime.py:77-83) */
+
+int64_t af_stem_input_bytes(int n, int t, int h, int w, int dtype);
+/* (n,3,t,h,w)-logical fp32 tensor with arbitrary element strides -> padded stem input */
+int af_pack_input_f32(const float* x, int n, int t, int h, int w,
+                      int64_t stride_n, int64_t stride_c, int64_t stride_t, int64_t stride_h, int64_t stride_w,
+                      int dtype, void* stem_in, void* stream);
+/* caller-layout uint8 clips (n,t,h,w,3), 0..255 RGB -> (x - mean[c]) / std[c] -> padded stem input */
+int af_pack_input_u8(const uint8_t* clips, int n, int t, int h, int w,
+                     const float mean[3], const float std_[3], int dtype, void* stem_in, void* stream);
+
+/* ---- layers ------------------------------------------------------------------------- */
+
+/* Conv3d(3->64,[kt,7,7],s[1,2,2],p[kt/2,3,3],bias=False)+BN+ReLU  (stem_helper.py:156-177).
+ * d->cin must be 3, in = padded stem input, out = [n][to][ho][wo][cout]. */
+int af_stem_conv_bn_relu(const af_conv_desc* d, const void* stem_in, const void* w_packed,
+                         const float* scale, const float* shift, void* out, void* stream);
+
+/* Conv3d(bias=False)+BN[+residual add][+ReLU] as one implicit-GEMM launch: the a/b/c convs of
+ * BottleneckTransform (resnet_helper.py:267-325), the projection shortcut and the add+ReLU of
+ * ResBlock (resnet_helper.py:411-444), FuseFastToSlow's conv_f2s+bn+relu (video_model_builder.py:121-143).
+ * Requires cin % 64 == 0 (16-bit) or cin % 32 == 0 (fp32) and cout % 64 == 0.
+ * `residual` (NULL or [n][to][ho][wo][cout]) is added before the ReLU.
+ * `out_ld` = channel stride of `out` rows in elements (>= cout; lets FuseFastToSlow write into
+ * the concatenated slow tensor), 0 means cout. */
+int af_conv3d_bn_act(const af_conv_desc* d, const void* in, const void* w_packed,
+                     const float* scale, const float* shift, const void* residual,
+                     void* out, int out_ld, void* stream);
+
+/* nn.MaxPool3d on NDHWC (stem_helper.py:168-170 [1,3,3]/[1,2,2]/[0,1,1];
+ * video_model_builder.py:474-480 [2,1,1]/[2,1,1]); padding behaves as -inf. */
+int af_maxpool3d(const af_pool_desc* d, const void* in, void* out, void* stream);
+
+/* ResNetBasicHead (head_helper.py:74-95): AvgPool3d(pool,stride 1) -> Linear(c -> num_classes).
+ * pooled (optional, may be NULL): fp32 [n][to*ho*wo][c] pooled features (the input of the
+ * nn.Linear that feature.py:105-114 hooks); logits: fp32 [n][to*ho*wo*num_classes]. */
+int af_avgpool_fc(const af_pool_desc* d, const void* in, const float* fc_w, const float* fc_b,
+                  int num_classes, float* pooled, float* logits, void* stream);
+
+/* ---- whole-forward op list ------------------------------------------------------------ */
+
+enum af_op_kind { AF_OP_STEM = 0, AF_OP_CONV = 1, AF_OP_MAXPOOL = 2, AF_OP_HEAD = 3,
+                  AF_OP_PACK_F32 = 4, AF_OP_PACK_U8 = 5 };
+
+typedef struct af_op {
+    int32_t kind;                    /* af_op_kind */
+    int32_t out_ld;
+    af_conv_desc conv;               /* STEM / CONV */
+    af_pool_desc pool;               /* MAXPOOL / HEAD */
+    const void* in;
+    const void* weight;              /* packed conv weight | fc weight */
+    const float* scale;              /* BN scale | fc bias */
+    const float* shift;
+    const void* residual;
+    void* out;                       /* activation | logits */
+    void* aux;                       /* HEAD: pooled features (optional) */
+    int32_t num_classes;
+    int32_t tag;                     /* caller-defined (e.g. layer class) - echoed by *_timed */
+    /* PACK_* only */
+    int64_t in_strides[5];           /* n,c,t,h,w element strides of the fp32 source */
+    float mean[3], std_[3];
+} af_op;
+
+/* Enqueue ops[0..n) in order on `stream` (AltFreezing: ResNet.forward, video_model_builder.py:561-578). */
+int af_run_ops(const af_op* ops, int n_ops, void* stream);
+/* Same, bracketing every op with hipEvents on `stream`; ms[i] = device time of op i.  Synchronises. */
+int af_run_ops_timed(const af_op* ops, int n_ops, void* stream, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AF_HIP_H */

@@ -1,0 +1,87 @@
+"""ctypes binding of libafhip.so (include/af_hip.h).  There is NO fallback: if the HIP library is
+missing or does not export the ABI this file declares, importing fails loudly."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libafhip.so")
+
+AF_F32, AF_BF16, AF_F16 = 0, 1, 2
+AF_OP_STEM, AF_OP_CONV, AF_OP_MAXPOOL, AF_OP_HEAD, AF_OP_PACK_F32, AF_OP_PACK_U8 = range(6)
+AF_ABI_VERSION = 1
+STEM_PAD_T, STEM_PAD_H, STEM_PAD_W_LEFT, STEM_PAD_W_TOTAL, STEM_CPAD = 2, 3, 3, 8, 4
+
+DTYPE_CODES = {"f32": AF_F32, "bf16": AF_BF16, "f16": AF_F16}
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "n", "t", "h", "w", "cin", "cout", "kt", "kh", "kw", "st", "sh", "sw", "pt", "ph", "pw",
+        "to", "ho", "wo", "relu", "dtype")]
+
+
+class PoolDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "n", "t", "h", "w", "c", "kt", "kh", "kw", "st", "sh", "sw", "pt", "ph", "pw", "to", "ho", "wo", "dtype")]
+
+
+class Op(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32), ("out_ld", C.c_int32),
+        ("conv", ConvDesc), ("pool", PoolDesc),
+        ("in_", C.c_void_p), ("weight", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p),
+        ("residual", C.c_void_p), ("out", C.c_void_p), ("aux", C.c_void_p),
+        ("num_classes", C.c_int32), ("tag", C.c_int32),
+        ("in_strides", C.c_int64 * 5),
+        ("mean", C.c_float * 3), ("std_", C.c_float * 3),
+    ]
+
+
+# name -> (restype, argtypes); this table is also what tests/test_abi.py checks against include/af_hip.h
+ABI = {
+    "af_version": (C.c_int, []),
+    "af_last_error": (C.c_char_p, []),
+    "af_device_count": (C.c_int, []),
+    "af_fold_bn": (C.c_int, [C.c_void_p] * 4 + [C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "af_packed_conv_weight_bytes": (C.c_int64, [C.c_int] * 6),
+    "af_pack_conv_weight": (C.c_int, [C.c_void_p] + [C.c_int] * 6 + [C.c_void_p, C.c_void_p]),
+    "af_packed_stem_weight_bytes": (C.c_int64, [C.c_int] * 4),
+    "af_pack_stem_weight": (C.c_int, [C.c_void_p] + [C.c_int] * 5 + [C.c_void_p, C.c_void_p]),
+    "af_stem_input_bytes": (C.c_int64, [C.c_int] * 5),
+    "af_pack_input_f32": (C.c_int, [C.c_void_p] + [C.c_int] * 4 + [C.c_int64] * 5 + [C.c_int, C.c_void_p, C.c_void_p]),
+    "af_pack_input_u8": (C.c_int, [C.c_void_p] + [C.c_int] * 4 + [C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                                                  C.c_int, C.c_void_p, C.c_void_p]),
+    "af_stem_conv_bn_relu": (C.c_int, [C.POINTER(ConvDesc)] + [C.c_void_p] * 6),
+    "af_conv3d_bn_act": (C.c_int, [C.POINTER(ConvDesc)] + [C.c_void_p] * 6 + [C.c_int, C.c_void_p]),
+    "af_maxpool3d": (C.c_int, [C.POINTER(PoolDesc), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "af_avgpool_fc": (C.c_int, [C.POINTER(PoolDesc)] + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 3),
+    "af_run_ops": (C.c_int, [C.POINTER(Op), C.c_int, C.c_void_p]),
+    "af_run_ops_timed": (C.c_int, [C.POINTER(Op), C.c_int, C.c_void_p, C.POINTER(C.c_float)]),
+}
+
+
+class AfError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "libafhip.so not found at %s - build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950); there is no CPU fallback for the HIP path" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in ABI.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    if lib.af_version() != AF_ABI_VERSION:
+        raise ImportError("libafhip.so ABI version %d, binding expects %d" % (lib.af_version(), AF_ABI_VERSION))
+    return lib
+
+
+lib = _load()
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        raise AfError("%s failed (%d): %s" % (what or "libafhip call", rc, lib.af_last_error().decode()))

@@ -1,0 +1,276 @@
+"""Drop-in for the reference classifier plugin ``model.classifier.i3d_ori``.
+
+Surface mirrored (same names, argument meaning, return values and error behaviour):
+
+* ``Classifier()`` -> ``.to(device)`` / ``.cuda()`` -> ``.eval()`` -> ``.load(ckpt)`` -> ``__call__(x)``
+  (reference altfreezing/model/_base.py:17-104, callers demo.py:403-404, test/af_realtime.py:68-69)
+* ``network`` / ``_warped_network`` attributes, ``network.state_dict()`` = the 320-key checkpoint layout
+  (``resnet.s1.pathway0_stem.conv.weight`` ... ``resnet.head.projection.bias``)
+* ``forward(images, noise=None, has_mask=None, freeze_backbone=False, return_feature_maps=False)``
+  -> ``{"final_output": (B,1) fp32 logits}``  (altfreezing/model/classifier/i3d_ori.py:92-104)
+* the last ``nn.Linear`` in ``.modules()`` is the head projection and sees the pooled
+  ``(B,1,1,1,2048)`` feature whenever somebody hooks it (altfreezing/feature.py:105-114)
+
+The parameters live in an ordinary ``nn.Module`` tree (so ``state_dict``/``load_state_dict``/``.to``
+behave exactly like the reference's), but no torch op computes the forward: it is executed by the
+HIP engine (engine.py -> libafhip.so).  There is no CPU or eager fallback - calling the model on a
+non-HIP tensor raises.
+"""
+import logging
+import math
+import os
+import traceback
+from collections import OrderedDict
+from typing import Dict, Optional, Tuple
+
+import torch
+from torch import nn
+
+from .arch import ConvSpec, NetSpec, i3d_r50_spec
+
+logger = logging.getLogger("af_mi355x")
+
+PRECISIONS = ("auto", "f32", "bf16", "f16")
+
+
+class _Node(nn.Module):
+    """Parameter container; only there to reproduce the reference's module/parameter names."""
+
+    def forward(self, *a, **k):            # pragma: no cover
+        raise RuntimeError("skeleton module: the forward is executed by the HIP engine, not by torch.nn")
+
+
+def _conv_module(cv: ConvSpec) -> nn.Conv3d:
+    return nn.Conv3d(cv.cin, cv.cout, cv.kernel, stride=cv.stride, padding=cv.pad, bias=False)
+
+
+def _bn_module(cv: ConvSpec) -> nn.BatchNorm3d:
+    bn = nn.BatchNorm3d(cv.cout, eps=1e-5, momentum=0.1)
+    if cv.final_bn:
+        bn.transform_final_bn = True
+    return bn
+
+
+def _attach(root: nn.Module, dotted: str, module: nn.Module):
+    parts = dotted.split(".")
+    cur = root
+    for p in parts[:-1]:
+        if not hasattr(cur, p):
+            cur.add_module(p, _Node())
+        cur = getattr(cur, p)
+    cur.add_module(parts[-1], module)
+
+
+def _init_like_reference(root: nn.Module, fc_std: float = 0.01, zero_init_final_bn: bool = True):
+    """Fresh-model init as the reference does it (slowfast/utils/weight_init_helper.py:10-43): conv
+    c2-MSRA, BN gamma 1 (0 on each block's last BN), beta 0, fc N(0, 0.01).  Only matters until load()."""
+    for m in root.modules():
+        if isinstance(m, nn.Conv3d):
+            nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+        elif isinstance(m, nn.BatchNorm3d):
+            final = getattr(m, "transform_final_bn", False) and zero_init_final_bn
+            m.weight.data.fill_(0.0 if final else 1.0)
+            m.bias.data.zero_()
+        elif isinstance(m, nn.Linear):
+            m.weight.data.normal_(mean=0.0, std=fc_std)
+            m.bias.data.zero_()
+
+
+class I3D8x8(nn.Module):
+    """The plugin's network module (``module_to_build`` of the reference Classifier)."""
+
+    def __init__(self, clip_size: int = 32, imsize: int = 224, precision: str = "auto", crop_size: int = 224) -> None:
+        super().__init__()
+        if precision not in PRECISIONS:
+            raise ValueError("precision must be one of %s" % (PRECISIONS,))
+        # the head pool is sized from DATA.CROP_SIZE=224 (defaults.py:277), not from imsize;
+        # crop_size is only changed by tests that run a shrunken network
+        self.spec: NetSpec = i3d_r50_spec(num_frames=clip_size, crop=crop_size)
+        self.clip_size, self.imsize, self.precision = clip_size, imsize, precision
+        self.resnet = _Node()
+        for cv in self.spec.convs():
+            _attach(self, cv.conv, _conv_module(cv))
+            _attach(self, cv.bn, _bn_module(cv))
+        _attach(self, "resnet.head.dropout", nn.Dropout(0.5))
+        _attach(self, self.spec.head, nn.Linear(self.spec.head_in, self.spec.num_classes, bias=True))
+        _init_like_reference(self)
+        self._packed: Dict[str, Tuple[tuple, object]] = {}      # dtype -> (signature, PackedWeights)
+        self._engines: Dict[tuple, object] = {}                 # (dtype, batch, dims) -> Engine
+
+    # -- weight / engine caches ---------------------------------------------------------------------
+    def _signature(self):
+        first = next(self.parameters())
+        ver = 0
+        for t in list(self.parameters()) + list(self.buffers()):
+            ver += t._version
+        return (str(first.device), first.data_ptr(), ver)
+
+    def _select_dtype(self) -> str:
+        if self.precision != "auto":
+            return self.precision
+        if torch.is_autocast_enabled():              # callers' amp=True (af_realtime.py:70,84)
+            return "bf16" if torch.get_autocast_dtype("cuda") == torch.bfloat16 else "f16"
+        return "f32"
+
+    def _engine(self, dtype: str, batch: int, dims, device):
+        from .engine import Engine, PackedWeights            # imports libafhip.so: fails loudly if absent
+        sig = self._signature()
+        cached = self._packed.get(dtype)
+        if cached is None or cached[0] != sig:
+            state = {k: v for k, v in self.state_dict().items()}
+            self._packed[dtype] = (sig, PackedWeights(self.spec, state, dtype, device))
+            self._engines = {k: e for k, e in self._engines.items() if k[0] != dtype}
+        key = (dtype, batch, tuple(dims))
+        if key not in self._engines:
+            self._engines[key] = Engine(self.spec, self._packed[dtype][1], batch, device, dims)
+        return self._engines[key]
+
+    # -- forward ------------------------------------------------------------------------------------------
+    def forward(self, images, noise=None, has_mask=None, freeze_backbone=False, return_feature_maps=False):
+        assert not freeze_backbone
+        if not isinstance(images, torch.Tensor) or images.dim() != 5 or images.size(1) != 3:
+            raise ValueError("images must be a (B,3,T,H,W) tensor")
+        if not images.is_cuda:
+            raise RuntimeError("the MI355X classifier only runs on a HIP device tensor (no CPU fallback); "
+                               "got a tensor on %s" % images.device)
+        if self.training:
+            raise RuntimeError("inference only: call .eval() first (BatchNorm running statistics are folded)")
+        dev = images.device
+        if next(self.parameters()).device != dev:
+            raise RuntimeError("model parameters are on %s but the input is on %s" % (next(self.parameters()).device, dev))
+        x = images if images.dtype == torch.float32 else images.float()
+        B, _, T, H, W = x.shape
+        with torch.cuda.device(dev):
+            eng = self._engine(self._select_dtype(), B, (T, H, W), dev)
+            logits, pooled = eng.run_f32(x)
+            pred = self._finish(eng, logits, pooled, B)
+        return {"final_output": pred}
+
+    def forward_clips_u8(self, clips_bthwc: torch.Tensor, mean=None, std=None):
+        """Fused caller prologue: uint8 (B,T,H,W,3) 0..255 RGB clips straight from the aligner; replaces
+        as_tensor/permute/sub/div of ``ClassifierSvc.infer_scores`` (test/af_realtime.py:77-83)."""
+        from .synth import pixel_mean_std_f32
+        if mean is None or std is None:
+            m, s = pixel_mean_std_f32()
+            mean, std = m.tolist(), s.tolist()
+        dev = clips_bthwc.device
+        B, T, H, W, _ = clips_bthwc.shape
+        with torch.cuda.device(dev):
+            eng = self._engine(self._select_dtype(), B, (T, H, W), dev)
+            logits, pooled = eng.run_u8(clips_bthwc.contiguous(), mean, std)
+            pred = self._finish(eng, logits, pooled, B)
+        return {"final_output": pred}
+
+    def _finish(self, eng, logits, pooled, B):
+        proj = self.resnet.head.projection
+        if proj._forward_hooks or proj._forward_pre_hooks:
+            # somebody (feature.py:105-114) listens on the head Linear: feed it the pooled feature in the
+            # reference's (N,T',H',W',C) layout so the hook sees the same input/output as upstream
+            feat = pooled.view((B,) + tuple(eng.head_dims) + (pooled.shape[-1],))
+            return proj(feat.clone()).reshape(B, -1)
+        return logits.clone().view(B, -1)
+
+
+def _unwrap_checkpoint(saved):
+    if isinstance(saved, dict):
+        for k in ("state_dict", "classifier_state_dict", "model_state_dict"):
+            if k in saved:
+                return saved[k]
+    return saved
+
+
+def _strip_prefix(k: str) -> str:
+    for p in ("module.", "network.", "_warped_network."):
+        if k.startswith(p):
+            return k[len(p):]
+    return k
+
+
+class Classifier(nn.Module):
+    """ModelBase + Classifier of the reference, for this one plugin."""
+
+    name = "i3d_ori"
+
+    def __init__(self, clip_size: int = 32, imsize: int = 224, precision: str = "auto",
+                 model_dir: Optional[str] = None, crop_size: int = 224):
+        super().__init__()
+        self._build_kwargs = dict(clip_size=clip_size, imsize=imsize, precision=precision, crop_size=crop_size)
+        self.model_dir = model_dir
+        self.network = self.build_network()
+        self._warped_network = self.network
+
+    @property
+    def module_to_build(self):
+        return I3D8x8
+
+    def build_network(self) -> nn.Module:
+        return self.module_to_build(**self._build_kwargs)
+
+    def forward(self, *input, **kwargs):
+        return self._warped_network(*input, **kwargs)
+
+    def parameters(self, recurse=True):
+        return self.network.parameters(recurse)
+
+    def freeze(self):
+        for p in self.parameters():
+            p.requires_grad = False
+
+    def find_last(self, epoch=-1, model_dir=None):
+        model_dir = model_dir or self.model_dir
+        if not model_dir or not os.path.exists(model_dir):
+            return None, -1
+        found = {}
+        for f in os.listdir(model_dir):
+            if f.startswith(self.name) and f.endswith(".pth"):
+                try:
+                    found[int(f.split(".")[0].split("_")[-1])] = os.path.join(model_dir, f)
+                except ValueError:
+                    continue
+        if not found:
+            return None, -1
+        if epoch == -1:
+            e = max(found)
+            return found[e], e
+        if epoch not in found:
+            raise RuntimeError("no checkpoint for epoch {} in {}".format(epoch, model_dir))
+        return found[epoch], epoch
+
+    def load(self, fullpath=None, epoch=-1, pretrained=None):
+        """Same contract as ModelBase.load (altfreezing/model/_base.py:39-104): returns (ok, epoch);
+        a missing/corrupt file (OSError / ValueError) is reported as (False, -1) WITHOUT raising."""
+        if fullpath is None:
+            fullpath, loaded_epoch = self.find_last(epoch)
+        else:
+            loaded_epoch = epoch
+        if fullpath is None:
+            if pretrained is None:
+                logger.info("No existing %s model found", self.name)
+                return False, -1
+            fullpath, loaded_epoch = pretrained, -1
+        try:
+            saved = torch.load(fullpath, map_location="cpu", weights_only=True)
+            sd = _unwrap_checkpoint(saved)
+            sd = OrderedDict((_strip_prefix(k), v) for k, v in sd.items())
+            param_dict = self.network.state_dict()
+            loadable = {k: v for k, v in sd.items() if k in param_dict and param_dict[k].shape == v.shape}
+            redundant = sorted(k for k in sd if k not in param_dict)
+            unmatch = sorted(k for k in sd if k in param_dict and param_dict[k].shape != sd[k].shape)
+            unfound = sorted(set(param_dict) - set(loadable) - set(unmatch))
+            if redundant:
+                logger.warning("%d keys are in the checkpoint but not in model %s", len(redundant), self.name)
+            if unfound:
+                logger.warning("%d keys are in model %s but not in the checkpoint", len(unfound), self.name)
+            if unmatch:
+                logger.warning("%d keys have unmatching shapes between checkpoint and model %s", len(unmatch), self.name)
+            param_dict.update(loadable)
+            self.network.load_state_dict(param_dict, strict=False)
+            logger.info("load weights from %s", fullpath)
+        except (ValueError, OSError) as err:
+            logger.warning("Failed loading existing training data for %s (%s): the model keeps its current weights",
+                           self.name, err)
+            return False, -1
+        except Exception:
+            logger.error(traceback.format_exc())
+            raise
+        return True, loaded_epoch

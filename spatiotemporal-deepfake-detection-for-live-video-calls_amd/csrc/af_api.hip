@@ -1,0 +1,80 @@
+// C-ABI glue: version / error text / device probe and the whole-forward op-list runner.
+#include "af_common.h"
+
+#include <vector>
+
+namespace af {
+
+static thread_local char g_err[512] = "";
+
+int set_error(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+static int run_one(const af_op& op, hipStream_t s) {
+    switch (op.kind) {
+        case AF_OP_STEM:
+            return af_stem_conv_bn_relu(&op.conv, op.in, op.weight, op.scale, op.shift, op.out, s);
+        case AF_OP_CONV:
+            return af_conv3d_bn_act(&op.conv, op.in, op.weight, op.scale, op.shift, op.residual, op.out, op.out_ld, s);
+        case AF_OP_MAXPOOL:
+            return af_maxpool3d(&op.pool, op.in, op.out, s);
+        case AF_OP_HEAD:
+            return af_avgpool_fc(&op.pool, op.in, (const float*)op.weight, op.scale, op.num_classes, (float*)op.aux,
+                                 (float*)op.out, s);
+        case AF_OP_PACK_F32:
+            return af_pack_input_f32((const float*)op.in, op.conv.n, op.conv.t, op.conv.h, op.conv.w, op.in_strides[0],
+                                     op.in_strides[1], op.in_strides[2], op.in_strides[3], op.in_strides[4],
+                                     op.conv.dtype, op.out, s);
+        case AF_OP_PACK_U8:
+            return af_pack_input_u8((const uint8_t*)op.in, op.conv.n, op.conv.t, op.conv.h, op.conv.w, op.mean, op.std_,
+                                    op.conv.dtype, op.out, s);
+        default:
+            return set_error(AF_ERR_ARG, "run_ops: unknown op kind %d", op.kind);
+    }
+}
+
+}  // namespace af
+
+extern "C" int af_version(void) { return AF_ABI_VERSION; }
+
+extern "C" const char* af_last_error(void) { return af::g_err; }
+
+extern "C" int af_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return af::set_error(AF_ERR_NO_DEVICE, "no HIP device visible");
+    return n;
+}
+
+extern "C" int af_run_ops(const af_op* ops, int n_ops, void* stream) {
+    AF_REQUIRE(ops && n_ops > 0, "run_ops: empty op list");
+    for (int i = 0; i < n_ops; ++i) {
+        int rc = af::run_one(ops[i], (hipStream_t)stream);
+        if (rc != AF_OK) return rc;
+    }
+    return AF_OK;
+}
+
+extern "C" int af_run_ops_timed(const af_op* ops, int n_ops, void* stream, float* ms) {
+    AF_REQUIRE(ops && n_ops > 0 && ms, "run_ops_timed: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    std::vector<hipEvent_t> ev(n_ops + 1);
+    for (auto& e : ev)
+        if (hipEventCreate(&e) != hipSuccess) return af::set_error(AF_ERR_LAUNCH, "run_ops_timed: hipEventCreate failed");
+    int rc = AF_OK;
+    (void)hipEventRecord(ev[0], s);
+    for (int i = 0; i < n_ops && rc == AF_OK; ++i) {
+        rc = af::run_one(ops[i], s);
+        (void)hipEventRecord(ev[i + 1], s);
+    }
+    hipError_t e = hipStreamSynchronize(s);
+    if (rc == AF_OK && e != hipSuccess) rc = af::set_error(AF_ERR_LAUNCH, "run_ops_timed: %s", hipGetErrorString(e));
+    if (rc == AF_OK)
+        for (int i = 0; i < n_ops; ++i) (void)hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]);
+    for (auto& ev_ : ev) (void)hipEventDestroy(ev_);
+    return rc;
+}

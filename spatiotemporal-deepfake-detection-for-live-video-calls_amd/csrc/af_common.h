@@ -1,0 +1,112 @@
+// Internal helpers shared by the gfx950 kernels of libafhip.so.  CDNA4 only: wave64, MFMA.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/af_hip.h"
+
+namespace af {
+
+int set_error(int code, const char* fmt, ...);
+
+#define AF_REQUIRE(cond, ...)                                    \
+    do {                                                         \
+        if (!(cond)) return af::set_error(AF_ERR_ARG, __VA_ARGS__); \
+    } while (0)
+
+#define AF_CHECK_LAUNCH(what)                                                        \
+    do {                                                                             \
+        hipError_t e__ = hipGetLastError();                                          \
+        if (e__ != hipSuccess)                                                       \
+            return af::set_error(AF_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e__)); \
+    } while (0)
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+static inline int dtype_size(int dt) { return dt == AF_F32 ? 4 : 2; }
+static inline bool dtype_ok(int dt) { return dt == AF_F32 || dt == AF_BF16 || dt == AF_F16; }
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// One 16-byte operand chunk per lane -> MFMA(s) on a 16x16 fp32 accumulator tile.
+//   16-bit: one v_mfma_f32_16x16x32 (8 k-values per lane, k = 8*(lane>>4)+j)
+//   fp32  : four v_mfma_f32_16x16x4_f32; instruction j takes element j of the chunk, so it
+//           reduces over k = {4*(lane>>4)+j}: both operands use the same k order, which is all
+//           a dot product needs (exact fp32 fma chain per output element).
+template <int DT> struct Mma;
+template <> struct Mma<AF_BF16> {
+    static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x4& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+};
+template <> struct Mma<AF_F16> {
+    static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x4& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+};
+template <> struct Mma<AF_F32> {
+    static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x4& c) {
+        f32x4 af = __builtin_bit_cast(f32x4, a), bf = __builtin_bit_cast(f32x4, b);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0], bf[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1], bf[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(af[2], bf[2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(af[3], bf[3], c, 0, 0, 0);
+    }
+};
+
+// element conversions (fp32 <-> storage type)
+template <int DT> struct Elem;
+template <> struct Elem<AF_F32> {
+    typedef float type;
+    static constexpr int EPC = 4;  // elements per 16-byte chunk
+    static __device__ __forceinline__ float to_f32(float v) { return v; }
+    static __device__ __forceinline__ float from_f32(float v) { return v; }
+};
+template <> struct Elem<AF_BF16> {
+    typedef __bf16 type;
+    static constexpr int EPC = 8;
+    static __device__ __forceinline__ float to_f32(__bf16 v) { return (float)v; }
+    static __device__ __forceinline__ __bf16 from_f32(float v) { return (__bf16)v; }
+};
+template <> struct Elem<AF_F16> {
+    typedef _Float16 type;
+    static constexpr int EPC = 8;
+    static __device__ __forceinline__ float to_f32(_Float16 v) { return (float)v; }
+    static __device__ __forceinline__ _Float16 from_f32(float v) { return (_Float16)v; }
+};
+
+// 4 consecutive channels <-> one vector store/load (16 B fp32, 8 B 16-bit)
+template <int DT> struct Vec4;
+template <> struct Vec4<AF_F32> {
+    static __device__ __forceinline__ void store(void* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+    static __device__ __forceinline__ f32x4 load(const void* p) { return *reinterpret_cast<const f32x4*>(p); }
+};
+template <> struct Vec4<AF_BF16> {
+    typedef __bf16 b4 __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ void store(void* p, f32x4 v) {
+        b4 o; o[0] = (__bf16)v[0]; o[1] = (__bf16)v[1]; o[2] = (__bf16)v[2]; o[3] = (__bf16)v[3];
+        *reinterpret_cast<b4*>(p) = o;
+    }
+    static __device__ __forceinline__ f32x4 load(const void* p) {
+        b4 i = *reinterpret_cast<const b4*>(p);
+        f32x4 o; o[0] = (float)i[0]; o[1] = (float)i[1]; o[2] = (float)i[2]; o[3] = (float)i[3];
+        return o;
+    }
+};
+template <> struct Vec4<AF_F16> {
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ void store(void* p, f32x4 v) {
+        h4 o; o[0] = (_Float16)v[0]; o[1] = (_Float16)v[1]; o[2] = (_Float16)v[2]; o[3] = (_Float16)v[3];
+        *reinterpret_cast<h4*>(p) = o;
+    }
+    static __device__ __forceinline__ f32x4 load(const void* p) {
+        h4 i = *reinterpret_cast<const h4*>(p);
+        f32x4 o; o[0] = (float)i[0]; o[1] = (float)i[1]; o[2] = (float)i[2]; o[3] = (float)i[3];
+        return o;
+    }
+};
+
+}  // namespace af

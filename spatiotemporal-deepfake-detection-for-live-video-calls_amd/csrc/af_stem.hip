@@ -1,0 +1,157 @@
+// Stem: Conv3d(3->64, [kt,7,7], stride [1,2,2], pad [kt/2,3,3], bias=False) + BN + ReLU
+// (reference altfreezing/slowfast/models/stem_helper.py:156-177; i3d: kt = 5).
+//
+// Cin = 3 is hostile to a K-contiguous implicit GEMM, so the prologue kernels (af_pack.hip) write the
+// clip as [N][T+4][H+6][W+8][4]: channel padded 3->4 and a ZERO HALO (2 | 3 | 3 left) around T/H/W.
+// With that layout
+//   * one (dt,dh) kernel row = 8 pixels x 4 channels = 32 K-values that are CONTIGUOUS in HBM
+//     (kw padded 7->8, the 8th tap and the 4th channel have zero weights),
+//   * the left halo (3) cancels the conv's -3 offset: the run for output column wo starts at padded
+//     pixel 2*wo, i.e. at a 16-byte-aligned address in every dtype,
+//   * no bounds checks at all: every tap of every output position reads real memory.
+// K = kt*7*32 (1120 for i3d, 66 % useful MACs) - the price of Cin=3 on an MFMA whose K is 32.
+//
+// A workgroup computes 256 output positions x all 64 channels.  Weights (A operand) for one dt slice
+// sit in LDS as [dh][chunk][64 ch][16 B] (conflict-free ds_read_b128); activation
+// fragments (B operand) are fetched straight from global memory / L2 as one aligned 16-byte load per
+// lane per MFMA-K-step - each input byte is reused by ~12 positions x kt through L1/L2.
+#include "af_common.h"
+
+namespace af {
+
+struct StemArgs {
+    const char* in;      // padded input
+    const char* w;       // packed [kt][kh][NCH][cout][16 B]
+    const float* scale;
+    const float* shift;
+    char* out;
+    int Tp, Hp, Wp;      // padded dims
+    int kt, kh;
+    int To, Ho, Wo;
+    long long M;
+};
+
+// NCH = 16-byte chunks per (dt,dh) K-row = 32 elements / EPC : fp32 8, 16-bit 4
+template <int DT>
+__global__ __launch_bounds__(256, 2) void stem_kernel(const StemArgs a) {
+    typedef Elem<DT> E;
+    constexpr int EPC = E::EPC;
+    constexpr int ES = 16 / EPC;
+    constexpr int NCH = 32 / EPC;
+    constexpr int KK = NCH / 4;             // fragment reads per K-row (fp32 2, 16-bit 1)
+    constexpr int COUT = 64, TN = 4, TM = 4;
+    constexpr int PIXB = 4 * ES;            // bytes per padded pixel
+
+    extern __shared__ uint4 wlds[];         // [kh][NCH][64]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int frow = lane & 15, fg = lane >> 4;
+    const long long m0 = (long long)blockIdx.x * 256 + wave * 64;
+
+    // per-lane activation base (bytes) for each of the wave's TM position tiles
+    long long xoff[TM];
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        long long m = m0 + j * 16 + frow;
+        if (m >= a.M) m = a.M - 1;                       // clamp: compute garbage-free, never stored
+        int wo = (int)(m % a.Wo); long long t1 = m / a.Wo;
+        int ho = (int)(t1 % a.Ho); long long t2 = t1 / a.Ho;
+        int to = (int)(t2 % a.To); long long n = t2 / a.To;
+        // padded coords of tap (dt=0,dh=0,dw=0): t = to, h = 2*ho, w = 2*wo
+        xoff[j] = ((((n * a.Tp + to) * a.Hp + 2 * ho) * a.Wp) + 2 * wo) * PIXB + fg * 16;
+    }
+    const long long row_bytes = (long long)a.Wp * PIXB;
+    const long long plane_bytes = row_bytes * a.Hp;
+
+    f32x4 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int slice_chunks = a.kh * NCH * COUT;          // uint4 per dt slice
+    for (int dt = 0; dt < a.kt; ++dt) {
+        __syncthreads();                                 // previous slice fully consumed
+        const uint4* wsrc = reinterpret_cast<const uint4*>(a.w) + (long long)dt * slice_chunks;
+        for (int i = tid; i < slice_chunks; i += 256) wlds[i] = wsrc[i];
+        __syncthreads();
+        for (int dh = 0; dh < a.kh; ++dh) {
+            const long long tap_off = dt * plane_bytes + dh * row_bytes;
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) {
+                uint4 af[TN], bf[TM];
+#pragma unroll
+                for (int j = 0; j < TM; ++j)
+                    bf[j] = *reinterpret_cast<const uint4*>(a.in + xoff[j] + tap_off + kk * 64);
+                const uint4* wl = wlds + ((dh * NCH) + kk * 4 + fg) * COUT + frow;
+#pragma unroll
+                for (int i = 0; i < TN; ++i) af[i] = wl[i * 16];
+#pragma unroll
+                for (int i = 0; i < TN; ++i)
+#pragma unroll
+                    for (int j = 0; j < TM; ++j) Mma<DT>::run(af[i], bf[j], acc[i][j]);
+            }
+        }
+    }
+
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+        const int ch = i * 16 + fg * 4;
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + ch);
+        const f32x4 sf = *reinterpret_cast<const f32x4*>(a.shift + ch);
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            const long long m = m0 + j * 16 + frow;
+            if (m < a.M) {
+                f32x4 v = acc[i][j] * sc + sf;
+                v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+                Vec4<DT>::store(a.out + (m * COUT + ch) * ES, v);
+            }
+        }
+    }
+}
+
+template <int DT>
+static int launch_stem(const StemArgs& a, hipStream_t stream) {
+    constexpr int NCH = 32 / Elem<DT>::EPC;
+    const int lds = a.kh * NCH * 64 * 16;
+    const long long blocks = (a.M + 255) / 256;
+    if (blocks > 0x7fffffffLL) return set_error(AF_ERR_ARG, "stem: grid too large");
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_kernel<DT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return set_error(AF_ERR_LAUNCH, "stem: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL((stem_kernel<DT>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
+    AF_CHECK_LAUNCH("stem_kernel");
+    return AF_OK;
+}
+
+}  // namespace af
+
+extern "C" int af_stem_conv_bn_relu(const af_conv_desc* d, const void* stem_in, const void* w_packed,
+                                    const float* scale, const float* shift, void* out, void* stream) {
+    using namespace af;
+    AF_REQUIRE(d && stem_in && w_packed && scale && shift && out, "stem: null argument");
+    AF_REQUIRE(dtype_ok(d->dtype), "stem: bad dtype %d", d->dtype);
+    AF_REQUIRE(d->cin == 3 && d->cout == 64, "stem: expects 3 -> 64 channels (got %d -> %d)", d->cin, d->cout);
+    AF_REQUIRE(d->kh == 7 && d->kw == 7 && d->sh == 2 && d->sw == 2 && d->st == 1 && d->ph == 3 && d->pw == 3,
+               "stem: expects a [kt,7,7] kernel, stride [1,2,2], pad [kt/2,3,3]");
+    AF_REQUIRE(d->kt >= 1 && d->kt <= 2 * AF_STEM_PAD_T + 1 && (d->kt & 1) && d->pt == d->kt / 2, "stem: bad kt/pt");
+    AF_REQUIRE(d->n > 0 && d->t > 0 && d->h > 0 && d->w > 0, "stem: bad dims");
+    const int to = d->t, ho = (d->h + 6 - 7) / 2 + 1, wo = (d->w + 6 - 7) / 2 + 1;
+    AF_REQUIRE(to == d->to && ho == d->ho && wo == d->wo, "stem: output dims mismatch");
+    AF_REQUIRE(aligned16(stem_in) && aligned16(w_packed) && aligned16(scale) && aligned16(shift) && aligned16(out),
+               "stem: buffers must be 16-byte aligned");
+    StemArgs a;
+    a.in = (const char*)stem_in; a.w = (const char*)w_packed; a.scale = scale; a.shift = shift; a.out = (char*)out;
+    a.Tp = d->t + 2 * AF_STEM_PAD_T; a.Hp = d->h + 2 * AF_STEM_PAD_H; a.Wp = d->w + AF_STEM_PAD_W_TOTAL;
+    a.kt = d->kt; a.kh = d->kh; a.To = to; a.Ho = ho; a.Wo = wo;
+    a.M = (long long)d->n * to * ho * wo;
+    // temporal halo is AF_STEM_PAD_T; a kernel with kt < 5 starts (PAD_T - pt) planes into it
+    a.in += (long long)(AF_STEM_PAD_T - d->pt) * a.Hp * a.Wp * 4 * dtype_size(d->dtype);
+    hipStream_t s = (hipStream_t)stream;
+    switch (d->dtype) {
+        case AF_F32: return launch_stem<AF_F32>(a, s);
+        case AF_BF16: return launch_stem<AF_BF16>(a, s);
+        default: return launch_stem<AF_F16>(a, s);
+    }
+}

@@ -1,0 +1,142 @@
+"""Thin test-side wrappers that call libafhip.so through its C ABI (af_mi355x._lib) on torch-owned
+device buffers.  Layout conversions (NCDHW <-> NDHWC) are done with torch: they are test scaffolding."""
+import ctypes as C
+
+import torch
+
+TORCH_DT = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}
+# stated tolerances of the per-layer and whole-net parity tests, relative to max|reference output|
+LAYER_TOL = {"f32": 2e-5, "f16": 4e-3, "bf16": 3e-2}
+
+
+def lib():
+    from af_mi355x import _lib
+    return _lib
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def to_ndhwc(x_ncdhw, dtype):
+    return x_ncdhw.permute(0, 2, 3, 4, 1).contiguous().to(device="cuda", dtype=TORCH_DT[dtype])
+
+
+def to_ncdhw(x_ndhwc):
+    return x_ndhwc.permute(0, 4, 1, 2, 3).float().cpu()
+
+
+def fold_bn(sd, prefix):
+    L = lib()
+    ts = [sd[prefix + s].float().cuda().contiguous() for s in (".weight", ".bias", ".running_mean", ".running_var")]
+    c = ts[0].numel()
+    scale = torch.empty(c, device="cuda")
+    shift = torch.empty(c, device="cuda")
+    L.check(L.lib.af_fold_bn(_p(ts[0]), _p(ts[1]), _p(ts[2]), _p(ts[3]), 1e-5, c, _p(scale), _p(shift), _stream()), "fold_bn")
+    return scale, shift
+
+
+def conv_bn_act(x_ndhwc, w_oidhw, scale, shift, stride, pad, relu, dtype, residual=None, out=None, out_ld=0):
+    L = lib()
+    code = L.DTYPE_CODES[dtype]
+    n, t, h, w, cin = x_ndhwc.shape
+    cout, cin2, kt, kh, kw = w_oidhw.shape
+    assert cin == cin2
+    d = L.ConvDesc()
+    d.n, d.t, d.h, d.w, d.cin, d.cout = n, t, h, w, cin, cout
+    d.kt, d.kh, d.kw = kt, kh, kw
+    d.st, d.sh, d.sw = stride
+    d.pt, d.ph, d.pw = pad
+    d.to, d.ho, d.wo = [(a + 2 * p - k) // s + 1 for a, p, k, s in zip((t, h, w), pad, (kt, kh, kw), stride)]
+    d.relu, d.dtype = int(relu), code
+    wsrc = w_oidhw.float().cuda().contiguous()
+    nbytes = L.lib.af_packed_conv_weight_bytes(cout, cin, kt, kh, kw, code)
+    packed = torch.empty(nbytes // (4 if dtype == "f32" else 2), dtype=TORCH_DT[dtype], device="cuda")
+    L.check(L.lib.af_pack_conv_weight(_p(wsrc), cout, cin, kt, kh, kw, code, _p(packed), _stream()), "pack_conv_weight")
+    if out is None:
+        out = torch.empty((n, d.to, d.ho, d.wo, cout), dtype=TORCH_DT[dtype], device="cuda")
+    L.check(L.lib.af_conv3d_bn_act(C.byref(d), _p(x_ndhwc), _p(packed), _p(scale), _p(shift), _p(residual), _p(out),
+                                   out_ld, _stream()), "conv3d_bn_act")
+    return out
+
+
+def pack_input_f32(x_ncdhw_dev, dtype):
+    L = lib()
+    code = L.DTYPE_CODES[dtype]
+    n, c, t, h, w = x_ncdhw_dev.shape
+    nbytes = L.lib.af_stem_input_bytes(n, t, h, w, code)
+    buf = torch.zeros(nbytes // (4 if dtype == "f32" else 2), dtype=TORCH_DT[dtype], device="cuda")
+    s = x_ncdhw_dev.stride()
+    L.check(L.lib.af_pack_input_f32(_p(x_ncdhw_dev), n, t, h, w, s[0], s[1], s[2], s[3], s[4], code, _p(buf), _stream()),
+            "pack_input_f32")
+    return buf
+
+
+def pack_input_u8(clips_dev, mean, std, dtype):
+    L = lib()
+    code = L.DTYPE_CODES[dtype]
+    n, t, h, w, _ = clips_dev.shape
+    nbytes = L.lib.af_stem_input_bytes(n, t, h, w, code)
+    buf = torch.zeros(nbytes // (4 if dtype == "f32" else 2), dtype=TORCH_DT[dtype], device="cuda")
+    m = (C.c_float * 3)(*mean)
+    s = (C.c_float * 3)(*std)
+    L.check(L.lib.af_pack_input_u8(_p(clips_dev), n, t, h, w, m, s, code, _p(buf), _stream()), "pack_input_u8")
+    return buf
+
+
+def stem_conv(stem_in, dims, w_oidhw, scale, shift, dtype):
+    L = lib()
+    code = L.DTYPE_CODES[dtype]
+    n, t, h, w = dims
+    cout, _, kt, kh, kw = w_oidhw.shape
+    d = L.ConvDesc()
+    d.n, d.t, d.h, d.w, d.cin, d.cout = n, t, h, w, 3, cout
+    d.kt, d.kh, d.kw, d.st, d.sh, d.sw, d.pt, d.ph, d.pw = kt, kh, kw, 1, 2, 2, kt // 2, 3, 3
+    d.to, d.ho, d.wo = t, (h + 6 - 7) // 2 + 1, (w + 6 - 7) // 2 + 1
+    d.relu, d.dtype = 1, code
+    wsrc = w_oidhw.float().cuda().contiguous()
+    nbytes = L.lib.af_packed_stem_weight_bytes(cout, kt, kh, code)
+    packed = torch.empty(nbytes // (4 if dtype == "f32" else 2), dtype=TORCH_DT[dtype], device="cuda")
+    L.check(L.lib.af_pack_stem_weight(_p(wsrc), cout, kt, kh, kw, code, _p(packed), _stream()), "pack_stem_weight")
+    out = torch.empty((n, d.to, d.ho, d.wo, cout), dtype=TORCH_DT[dtype], device="cuda")
+    L.check(L.lib.af_stem_conv_bn_relu(C.byref(d), _p(stem_in), _p(packed), _p(scale), _p(shift), _p(out), _stream()),
+            "stem_conv_bn_relu")
+    return out
+
+
+def maxpool(x_ndhwc, kernel, stride, pad, dtype):
+    L = lib()
+    n, t, h, w, c = x_ndhwc.shape
+    d = L.PoolDesc()
+    d.n, d.t, d.h, d.w, d.c = n, t, h, w, c
+    d.kt, d.kh, d.kw = kernel
+    d.st, d.sh, d.sw = stride
+    d.pt, d.ph, d.pw = pad
+    d.to, d.ho, d.wo = [(a + 2 * p - k) // s + 1 for a, p, k, s in zip((t, h, w), pad, kernel, stride)]
+    d.dtype = L.DTYPE_CODES[dtype]
+    out = torch.empty((n, d.to, d.ho, d.wo, c), dtype=TORCH_DT[dtype], device="cuda")
+    L.check(L.lib.af_maxpool3d(C.byref(d), _p(x_ndhwc), _p(out), _stream()), "maxpool3d")
+    return out
+
+
+def avgpool_fc(x_ndhwc, pool, fc_w, fc_b, dtype):
+    L = lib()
+    n, t, h, w, c = x_ndhwc.shape
+    d = L.PoolDesc()
+    d.n, d.t, d.h, d.w, d.c = n, t, h, w, c
+    d.kt, d.kh, d.kw = pool
+    d.st = d.sh = d.sw = 1
+    d.pt = d.ph = d.pw = 0
+    d.to, d.ho, d.wo = t - pool[0] + 1, h - pool[1] + 1, w - pool[2] + 1
+    d.dtype = L.DTYPE_CODES[dtype]
+    k = fc_w.shape[0]
+    pos = d.to * d.ho * d.wo
+    pooled = torch.empty((n, pos, c), device="cuda")
+    logits = torch.empty((n, pos * k), device="cuda")
+    fw, fb = fc_w.float().cuda().contiguous(), fc_b.float().cuda().contiguous()
+    L.check(L.lib.af_avgpool_fc(C.byref(d), _p(x_ndhwc), _p(fw), _p(fb), k, _p(pooled), _p(logits), _stream()), "avgpool_fc")
+    return pooled, logits

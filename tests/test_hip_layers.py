@@ -1,0 +1,184 @@
+"""GPU: every HIP kernel, called through the C ABI, against (a) the golden outputs the reference's own
+layer modules produced (tests/golden/f3_kats.*) and (b) the oracle on further seeded shapes.
+
+Tolerances (relative to max|expected|, see hip_helpers.LAYER_TOL): fp32 2e-5 (exact-fp32 MFMA, only the
+summation order differs from oneDNN), fp16 4e-3, bf16 3e-2 (8-bit mantissa operands, fp32 accumulate)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import ROOT
+
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import i3d_oracle as oracle  # noqa: E402
+import hip_helpers as hh  # noqa: E402
+from af_mi355x import synth  # noqa: E402
+from test_oracle import _kat_input, _kat_state, run_oracle_kat  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+DTYPES = ["f32", "f16", "bf16"]
+
+
+def _close(got, want, dtype, what, scale=1.0):
+    want = want if torch.is_tensor(want) else torch.from_numpy(np.asarray(want))
+    got = got.float().cpu().reshape(want.shape)
+    ref = want.abs().max().item() + 1e-12
+    err = (got - want).abs().max().item()
+    assert err <= hh.LAYER_TOL[dtype] * scale * ref, "%s [%s]: max|d|=%.3e vs max|ref|=%.3e" % (what, dtype, err, ref)
+
+
+def hip_block(x_ncdhw, sd, p, stride, dtype):
+    x = hh.to_ndhwc(x_ncdhw, dtype)
+    wa = sd[p + ".branch2.a.weight"]
+    tk = wa.shape[2]
+    a = hh.conv_bn_act(x, wa, *hh.fold_bn(sd, p + ".branch2.a_bn"), (1, 1, 1), (tk // 2, 0, 0), True, dtype)
+    b = hh.conv_bn_act(a, sd[p + ".branch2.b.weight"], *hh.fold_bn(sd, p + ".branch2.b_bn"), (1, stride, stride),
+                       (0, 1, 1), True, dtype)
+    if (p + ".branch1.weight") in sd:
+        sc = hh.conv_bn_act(x, sd[p + ".branch1.weight"], *hh.fold_bn(sd, p + ".branch1_bn"), (1, stride, stride),
+                            (0, 0, 0), False, dtype)
+    else:
+        sc = x
+    out = hh.conv_bn_act(b, sd[p + ".branch2.c.weight"], *hh.fold_bn(sd, p + ".branch2.c_bn"), (1, 1, 1), (0, 0, 0),
+                         True, dtype, residual=sc)
+    return hh.to_ncdhw(out)
+
+
+def hip_stem(x_ncdhw, sd, p, dtype):
+    xd = x_ncdhw.cuda()
+    n, _, t, h, w = xd.shape
+    sin = hh.pack_input_f32(xd, dtype)
+    y = hh.stem_conv(sin, (n, t, h, w), sd[p + ".conv.weight"], *hh.fold_bn(sd, p + ".bn"), dtype)
+    y = hh.maxpool(y, (1, 3, 3), (1, 2, 2), (0, 1, 1), dtype)
+    return hh.to_ncdhw(y)
+
+
+def run_hip_kat(case, dtype):
+    sd, x, name, kind = _kat_state(case), _kat_input(case), case["name"], case["kind"]
+    if kind == "stem":
+        return hip_stem(x, sd, name, dtype)
+    if kind == "block":
+        return hip_block(x, sd, name, case["stride"], dtype)
+    if kind == "maxpool":
+        return hh.to_ncdhw(hh.maxpool(hh.to_ndhwc(x, dtype), case["kernel"], case["stride"], case["pad"], dtype))
+    if kind == "head":
+        _, logits = hh.avgpool_fc(hh.to_ndhwc(x, dtype), case["pool"], sd[name + ".projection.weight"],
+                                  sd[name + ".projection.bias"], dtype)
+        return logits.cpu()
+    if kind == "fuse":
+        k, a = case["kernel"], case["alpha"]
+        y = hh.conv_bn_act(hh.to_ndhwc(x, dtype), sd[name + ".conv_f2s.weight"], *hh.fold_bn(sd, name + ".bn"),
+                           (a, 1, 1), (k // 2, 0, 0), True, dtype)
+        return hh.to_ncdhw(y)
+    raise KeyError(kind)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_golden_kats(golden_f3, dtype):
+    cases, arrays = golden_f3
+    for case in cases:
+        want = torch.from_numpy(arrays[case["name"] + "_out"])
+        if dtype != "f32" and case["kind"] == "maxpool":
+            want = want.to(hh.TORCH_DT[dtype]).float()          # max-pool of rounded inputs is exact
+        got = run_hip_kat(case, dtype)
+        _close(got, want, dtype, case["name"], scale=3.0 if case["kind"] in ("block", "stem") else 1.0)
+
+
+def test_fold_bn_matches_torch():
+    sd = synth.fill_layout([("bn.weight", (256,), "float32"), ("bn.bias", (256,), "float32"),
+                            ("bn.running_mean", (256,), "float32"), ("bn.running_var", (256,), "float32")], 77)
+    scale, shift = hh.fold_bn(sd, "bn")
+    x = synth.synthetic_tensor((3, 256, 2, 2, 2), 78)
+    want = F.batch_norm(x, sd["bn.running_mean"], sd["bn.running_var"], sd["bn.weight"], sd["bn.bias"], False, 0.1, 1e-5)
+    got = x * scale.cpu().view(1, -1, 1, 1, 1) + shift.cpu().view(1, -1, 1, 1, 1)
+    assert (got - want).abs().max().item() <= 2e-6
+
+
+CONV_CASES = [
+    # name, cin, cout, kernel, stride, pad, in dims (n,t,h,w), relu, residual
+    ("1x1x1", 64, 256, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 3, 9, 7), False, False),
+    ("1x1x1_res_relu", 256, 64, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 2, 11, 13), True, True),
+    ("1x1x1_s2", 256, 512, (1, 1, 1), (1, 2, 2), (0, 0, 0), (2, 2, 9, 11), False, False),
+    ("3x1x1", 256, 64, (3, 1, 1), (1, 1, 1), (1, 0, 0), (1, 5, 6, 7), True, False),
+    ("1x3x3", 64, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), (2, 2, 13, 12), True, False),
+    ("1x3x3_s2", 128, 128, (1, 3, 3), (1, 2, 2), (0, 1, 1), (1, 3, 14, 15), True, False),
+    ("3x3x3_synthetic", 64, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 4, 9, 10), True, False),
+    ("5x1x1_t_stride8", 64, 128, (5, 1, 1), (8, 1, 1), (2, 0, 0), (1, 32, 4, 5), True, False),
+    ("big_m_tail", 64, 64, (1, 1, 1), (1, 1, 1), (0, 0, 0), (3, 7, 17, 19), False, False),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv_vs_oracle(case, dtype):
+    name, cin, cout, k, s, p, dims, relu, use_res = case
+    seed = 1000 + sum(map(ord, name))
+    lay = [("w.weight", (cout, cin) + k, "float32"), ("bn.weight", (cout,), "float32"), ("bn.bias", (cout,), "float32"),
+           ("bn.running_mean", (cout,), "float32"), ("bn.running_var", (cout,), "float32")]
+    sd = synth.fill_layout(lay, seed)
+    x = synth.synthetic_tensor((dims[0], cin) + dims[1:], seed)
+    if dtype != "f32":                       # same rounded operands for both sides: isolates the kernel
+        x = x.to(hh.TORCH_DT[dtype]).float()
+        sd["w.weight"] = sd["w.weight"].to(hh.TORCH_DT[dtype]).float()
+    want = oracle.conv_bn_act(x.double(), sd["w.weight"].double(), {kk: v.double() for kk, v in sd.items()}, "bn", s, p, False)
+    res = None
+    if use_res:
+        res = synth.synthetic_tensor(tuple(want.shape), seed + 1)
+        if dtype != "f32":
+            res = res.to(hh.TORCH_DT[dtype]).float()
+        want = want + res.double()
+    if relu:
+        want = F.relu(want)
+    got = hh.conv_bn_act(hh.to_ndhwc(x, dtype), sd["w.weight"], *hh.fold_bn(sd, "bn"), s, p, relu, dtype,
+                         residual=None if res is None else hh.to_ndhwc(res, dtype))
+    tol = {"f32": 2e-6, "f16": 1.5e-3, "bf16": 1.2e-2}[dtype]     # operands pre-rounded: only output rounding + fp32 accumulation remain
+    got = hh.to_ncdhw(got).double()
+    err = (got - want).abs().max().item()
+    assert err <= tol * (want.abs().max().item() + 1e-9), "%s[%s] err %.3e" % (name, dtype, err)
+
+
+def test_conv_out_ld_writes_into_concat_buffer():
+    """FuseFastToSlow concatenates by channel: the conv writes at a channel offset of a wider tensor."""
+    dtype = "f32"
+    lay = [("w.weight", (64, 64, 1, 1, 1), "float32"), ("bn.weight", (64,), "float32"), ("bn.bias", (64,), "float32"),
+           ("bn.running_mean", (64,), "float32"), ("bn.running_var", (64,), "float32")]
+    sd = synth.fill_layout(lay, 5)
+    x = synth.synthetic_tensor((1, 64, 2, 5, 5), 6)
+    wide = torch.full((1, 2, 5, 5, 192), 7.0, device="cuda")
+    view = wide.view(-1, 192)[:, 128:]
+    assert view.data_ptr() % 16 == 0
+    hh.conv_bn_act(hh.to_ndhwc(x, dtype), sd["w.weight"], *hh.fold_bn(sd, "bn"), (1, 1, 1), (0, 0, 0), True, dtype,
+                   out=view, out_ld=192)
+    want = oracle.conv_bn_act(x, sd["w.weight"], sd, "bn", (1, 1, 1), (0, 0, 0), True).permute(0, 2, 3, 4, 1)
+    assert torch.all(wide[..., :128] == 7.0)
+    assert (wide[..., 128:].cpu() - want).abs().max().item() <= 1e-5
+
+
+def test_input_prologue_u8_matches_callers():
+    u8 = synth.synthetic_clips_u8(2, seed=3, kind="uniform", num_frames=3, size=10)
+    x = synth.normalize_like_callers(u8)                       # (B,3,T,H,W) view, channels-last strides
+    mean, std = synth.pixel_mean_std_f32()
+    a = hh.pack_input_u8(u8.cuda(), mean.tolist(), std.tolist(), "f32")
+    b = hh.pack_input_f32(x.cuda(), "f32")
+    c = hh.pack_input_f32(x.contiguous().cuda(), "f32")        # NCDHW-contiguous source (feature.py:123)
+    assert torch.equal(a, b) and torch.equal(b, c)
+    vol = b.view(2, 3 + 4, 10 + 6, 10 + 8, 4)
+    assert torch.equal(vol[:, 2:5, 3:13, 3:13, :3].cpu(), x.permute(0, 2, 3, 4, 1))
+    assert vol[..., 3].abs().max().item() == 0 and vol[:, :2].abs().max().item() == 0
+
+
+def test_argument_errors_are_reported():
+    import ctypes as C
+    L = hh.lib()
+    d = L.ConvDesc()
+    rc = L.lib.af_conv3d_bn_act(C.byref(d), None, None, None, None, None, None, 0, None)
+    assert rc == -1 and b"null" in L.lib.af_last_error()
+    x = torch.zeros((1, 1, 4, 4, 48), device="cuda")
+    with pytest.raises(L.AfError, match="multiple of"):
+        hh.conv_bn_act(x, torch.zeros(64, 48, 1, 1, 1), torch.ones(64, device="cuda"), torch.zeros(64, device="cuda"),
+                       (1, 1, 1), (0, 0, 0), False, "f32")

@@ -1,0 +1,118 @@
+"""CPU: host-side logic of the drop-in (no compute calls): checkpoint layout, load() behaviour table
+generated from the reference's ModelBase.load, error behaviour, and the C ABI surface."""
+import os
+import re
+import tempfile
+
+import pytest
+import torch
+
+from conftest import ROOT, load_json
+from af_mi355x import arch, synth
+from af_mi355x.classifier import Classifier
+
+
+@pytest.fixture(scope="module")
+def clf():
+    return Classifier().eval()
+
+
+def test_state_dict_layout_equals_reference(clf):
+    lay = load_json("layout.json")["entries"]
+    mine = [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in clf.network.state_dict().items()]
+    assert mine == lay
+    both = list(clf.state_dict().keys())
+    assert len(both) == 640 and both[0].startswith("network.") and both[320].startswith("_warped_network.")
+    assert sum(p.numel() for p in clf.parameters()) == 27225921
+
+
+def test_last_linear_is_head_projection(clf):
+    lin = [m for m in clf.modules() if isinstance(m, torch.nn.Linear)][-1]
+    assert lin is clf.network.resnet.head.projection and lin.in_features == 2048 and lin.out_features == 1
+
+
+def test_load_behaviour_table(clf):
+    """Every row of tests/golden/f4_load.json was produced by the reference's ModelBase.load."""
+    rows = {r["case"]: r for r in load_json("f4_load.json")["rows"]}
+    base = synth.synthetic_state_dict(seed=3)
+    probe, other = "resnet.head.projection.bias", "resnet.s1.pathway0_stem.bn.bias"
+    with tempfile.TemporaryDirectory() as td:
+        def run(name, obj=None, path=None, **kw):
+            clf.load_state_dict({k: torch.zeros_like(v) for k, v in clf.state_dict().items()})
+            p = path or os.path.join(td, name + ".pth")
+            if obj is not None:
+                torch.save(obj, p)
+            ret = clf.load(p, **kw)
+            cur = clf.network.state_dict()
+            want = rows[name]
+            assert list(ret) == want["ret"], name
+            if "probe_loaded" in want:
+                assert bool(torch.equal(cur[probe], base[probe])) == want["probe_loaded"], name
+                assert bool(torch.equal(cur[other], base[other])) == want["other_loaded"], name
+
+        run("raw", base)
+        run("wrap_state_dict", {"state_dict": base, "epoch": 7})
+        run("wrap_classifier_state_dict", {"classifier_state_dict": base})
+        run("wrap_model_state_dict", {"model_state_dict": base})
+        for pfx in ("module.", "network.", "_warped_network."):
+            run("prefix_" + pfx.strip("._"), {pfx + k: v for k, v in base.items()})
+        run("prefix_double", {"module.network." + k: v for k, v in base.items()})
+        run("extra_key", dict(base, **{"resnet.extra.weight": torch.ones(3)}))
+        run("missing_probe", {k: v for k, v in base.items() if k != probe})
+        bad = dict(base)
+        bad[probe] = torch.ones(5)
+        run("shape_mismatch_probe", bad)
+        run("missing_file", path=os.path.join(td, "does_not_exist.pth"))
+        run("epoch_kw", base, epoch=12)
+    assert clf.load() == (False, -1)                        # no path, no model_dir, no pretrained
+
+
+def test_find_last_picks_highest_epoch():
+    with tempfile.TemporaryDirectory() as td:
+        c = Classifier(model_dir=td)
+        sd = c.network.state_dict()
+        for e in (3, 11, 7):
+            torch.save(sd, os.path.join(td, "i3d_ori_%d.pth" % e))
+        assert c.load() == (True, 11)
+        assert c.load(epoch=7) == (True, 7)
+
+
+def test_forward_contract_errors(clf):
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        clf(torch.zeros(1, 3, 32, 224, 224))
+    with pytest.raises(ValueError):
+        clf(torch.zeros(3, 32, 224, 224))
+    with pytest.raises(AssertionError):
+        clf(torch.zeros(1, 3, 32, 224, 224), freeze_backbone=True)
+
+
+def test_fresh_init_matches_reference_policy():
+    c = Classifier()
+    n = c.network.resnet
+    assert float(n.s2.pathway0_res0.branch2.c_bn.weight.abs().sum()) == 0.0      # ZERO_INIT_FINAL_BN
+    assert float(n.s2.pathway0_res0.branch2.a_bn.weight.min()) == 1.0
+    assert float(n.head.projection.bias.abs().sum()) == 0.0
+    assert abs(float(n.head.projection.weight.std()) - 0.01) < 2e-3
+
+
+def test_c_abi_exports_every_declared_symbol():
+    from af_mi355x import _lib
+    hdr = open(os.path.join(ROOT, "include", "af_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(af_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_lib.ABI), declared ^ set(_lib.ABI)
+    for name in declared:
+        assert hasattr(_lib.lib, name)
+    assert _lib.lib.af_version() == 1
+    import ctypes as C
+    assert C.sizeof(_lib.ConvDesc) == 20 * 4 and C.sizeof(_lib.PoolDesc) == 18 * 4
+
+
+def test_abi_rejects_bad_arguments_without_a_gpu():
+    from af_mi355x import _lib
+    import ctypes as C
+    d = _lib.ConvDesc()
+    assert _lib.lib.af_conv3d_bn_act(C.byref(d), None, None, None, None, None, None, 0, None) == -1
+    assert b"null" in _lib.lib.af_last_error()
+    assert _lib.lib.af_packed_conv_weight_bytes(64, 64, 1, 3, 3, 1) == 64 * 64 * 9 * 2
+    assert _lib.lib.af_stem_input_bytes(1, 32, 224, 224, 0) == 36 * 230 * 232 * 4 * 4
