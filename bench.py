@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""clips/s of the AltFreezing i3d_ori forward on MI355X (BASELINE.json metric), one JSON line on rank 0.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 16] [--dtype bf16]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N
+
+A step = one `model.forward(clip_batch)` of the drop-in Classifier on a (B,3,32,224,224) fp32 normalised
+batch already resident in HBM (the callers' channels-last strided tensor), B = 16 clips per GPU
+(BASELINE config[1]); with N > 1 every rank runs its own 16 clips and the step ends with the RCCL
+all-gather of the (N*16, 1) logits (config[2], weak scaling).  Weights are the seeded synthetic checkpoint
+W(0) in the reference's state_dict layout; clips are seeded synthetic uint8 face crops.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}    # dense MFMA, MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def cpu_baseline(sd, u8, threads_all):
+    """The oracle (PyTorch-CPU restatement of the reference forward, pinned by tests/golden) timed on the
+    host cores: a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import i3d_oracle as oracle
+    x = oracle.normalize(u8)
+    torch.set_num_threads(threads_all)
+    with torch.no_grad():
+        oracle.forward(sd, x[:1])                                   # warm-up (first call pages oneDNN in)
+        t0 = time.perf_counter()
+        ref = oracle.forward(sd, x)
+        t_all = time.perf_counter() - t0
+        torch.set_num_threads(1)
+        t0 = time.perf_counter()
+        oracle.forward(sd, x[:1])
+        t_one = time.perf_counter() - t0
+    torch.set_num_threads(threads_all)
+    return ref, {"value": round(x.shape[0] / t_all, 4), "unit": "clips/s", "cores": threads_all, "kind": "port",
+                 "sample": "%d clips (32x3x224x224, fp32) in one batch, PyTorch CPU oracle, %d threads; "
+                           "1 clip on 1 thread: %.3f clips/s" % (x.shape[0], threads_all, 1.0 / t_one)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16, help="clips per GPU")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
+    ap.add_argument("--cpu-clips", type=int, default=4, help="clips in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--layers-json", default=None, help="write per-layer device times / rates to this file")
+    args = ap.parse_args()
+
+    import af_mi355x  # noqa: F401
+    from af_mi355x import _lib, parallel, synth
+    from af_mi355x.classifier import Classifier
+    from af_mi355x.engine import TAG_NAMES
+
+    rank, local_rank, world = parallel.init()
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    B = args.batch
+
+    sd = synth.synthetic_state_dict(seed=0)
+    clf = Classifier(precision=args.dtype)
+    clf.network.load_state_dict(sd)
+    clf = clf.to(dev).eval()
+    u8 = synth.synthetic_clips_u8(B, seed=2026 + rank, kind="uniform")
+    x = synth.normalize_like_callers(u8.to(dev))                       # (B,3,32,224,224) fp32, channels-last strides
+    gathered = torch.empty((world * B, 1), dtype=torch.float32, device=dev)
+
+    def step():
+        y = clf(x)["final_output"]
+        return parallel.gather_logits(y, world * B, gathered)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    with torch.inference_mode():
+        for _ in range(args.warmup):
+            out = step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step()
+        fence()
+        dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    clips_per_s = world * B * args.steps / dt
+
+    line = {
+        "metric": "clips/sec (32x3x224x224)", "value": round(clips_per_s, 2), "unit": "clips/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": "AltFreezing i3d_ori (I3D-R50) forward, batch=%d clips/GPU of 32x3x224x224, "
+                               "synthetic checkpoint W(0), model.forward(clip) on HBM-resident fp32 input" % B,
+                   "global_batch": world * B, "parallelism": "dp%d + all-gather of logits" % world},
+    }
+
+    if rank == 0 and world == 1:
+        eng = clf.network._engines[(args.dtype, B, (32, 224, 224))]
+        total_macs = sum(eng.op_macs)
+        line["model_tflops_per_s"] = round(2 * total_macs / B * clips_per_s / 1e12, 2)
+        if not args.no_roofline:
+            reps = 5
+            acc = [0.0] * eng.n_ops
+            with torch.inference_mode():
+                for _ in range(reps):
+                    ms = eng.run_timed()
+                    acc = [a + m for a, m in zip(acc, ms)]
+            ms = [a / reps for a in acc]
+            # per kernel instantiation (conv variants) and per layer class
+            per_kernel, per_class = {}, {}
+            for i in range(eng.n_ops):
+                op = eng.ops[i]
+                cls = TAG_NAMES[op.tag]
+                c = per_class.setdefault(cls, {"ms": 0.0, "macs": 0, "launches": 0})
+                c["ms"] += ms[i]; c["macs"] += eng.op_macs[i]; c["launches"] += 1
+                if op.kind == _lib.AF_OP_CONV:
+                    import ctypes as C
+                    kname = _lib.lib.af_conv_variant_name(_lib.lib.af_conv_variant(C.byref(op.conv))).decode()
+                elif op.kind == _lib.AF_OP_STEM:
+                    kname = "stem_kernel"
+                else:
+                    continue
+                k = per_kernel.setdefault(kname, {"ms": 0.0, "macs": 0, "launches": 0})
+                k["ms"] += ms[i]; k["macs"] += eng.op_macs[i]; k["launches"] += 1
+            if args.layers_json:
+                es = 4 if args.dtype == "f32" else 2
+                rows = []
+                for i in range(eng.n_ops):
+                    op = eng.ops[i]
+                    row = {"i": i, "name": eng.op_names[i], "class": TAG_NAMES[op.tag], "ms": round(ms[i], 4)}
+                    if op.kind in (_lib.AF_OP_CONV, _lib.AF_OP_STEM):
+                        cd = op.conv
+                        m = cd.n * cd.to * cd.ho * cd.wo
+                        byts = es * (cd.n * cd.t * cd.h * cd.w * cd.cin + m * cd.cout * (2 if op.residual else 1)
+                                     + cd.cout * cd.cin * cd.kt * cd.kh * cd.kw)
+                        row.update({"M": m, "N": cd.cout, "K": cd.cin * cd.kt * cd.kh * cd.kw,
+                                    "tflops": round(2 * eng.op_macs[i] / ms[i] / 1e9, 1),
+                                    "alg_GBs": round(byts / ms[i] / 1e6, 0)})
+                    rows.append(row)
+                with open(args.layers_json, "w") as f:
+                    json.dump(rows, f, indent=0)
+            dom = max(per_kernel, key=lambda k: per_kernel[k]["ms"])
+            d = per_kernel[dom]
+            achieved = 2 * d["macs"] / (d["ms"] * 1e-3) / 1e12
+            line["roofline"] = {
+                "bound": "mfma", "kernel": dom, "launches_per_step": d["launches"],
+                "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2),
+                "algorithmic_gflop_per_launch": round(2 * d["macs"] / d["launches"] / 1e9, 3),
+                "achieved": round(achieved, 2), "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
+                "frac": round(achieved / PEAK_TFLOPS[args.dtype], 4), "traffic": None,
+            }
+            line["device_ms_per_step"] = round(sum(ms), 3)
+            line["classes"] = {k: {"ms": round(v["ms"], 3), "launches": v["launches"],
+                                   "tflops": round(2 * v["macs"] / max(v["ms"], 1e-9) / 1e9, 1) if v["macs"] else None}
+                               for k, v in sorted(per_class.items(), key=lambda kv: -kv[1]["ms"])}
+        if args.cpu_clips > 0:
+            n = min(args.cpu_clips, B)
+            try:
+                cores = len(os.sched_getaffinity(0))
+            except AttributeError:
+                cores = os.cpu_count() or 1
+            ref, cb = cpu_baseline(sd, u8[:n], max(1, min(cores, 16)))     # the box's CPU share for one GPU is 16
+            line["cpu_baseline"] = cb
+            line["max_abs_logit_err_vs_cpu_fp32"] = float((out[:n].float().cpu() - ref).abs().max())
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -116,6 +116,11 @@ int af_conv3d_bn_act(const af_conv_desc* d, const void* in, const void* w_packed
                      const float* scale, const float* shift, const void* residual,
                      void* out, int out_ld, void* stream);
 
+/* which tile variant af_conv3d_bn_act launches for `d` (>= 0) and its kernel name: lets a profiler
+ * attribute per-layer device time and FLOPs to a kernel instantiation (bench.py roofline). */
+int af_conv_variant(const af_conv_desc* d);
+const char* af_conv_variant_name(int variant);
+
 /* nn.MaxPool3d on NDHWC (stem_helper.py:168-170 [1,3,3]/[1,2,2]/[0,1,1];
  * video_model_builder.py:474-480 [2,1,1]/[2,1,1]); padding behaves as -inf. */
 int af_maxpool3d(const af_pool_desc* d, const void* in, void* out, void* stream);

@@ -53,6 +53,8 @@ ABI = {
                                                                   C.c_int, C.c_void_p, C.c_void_p]),
     "af_stem_conv_bn_relu": (C.c_int, [C.POINTER(ConvDesc)] + [C.c_void_p] * 6),
     "af_conv3d_bn_act": (C.c_int, [C.POINTER(ConvDesc)] + [C.c_void_p] * 6 + [C.c_int, C.c_void_p]),
+    "af_conv_variant": (C.c_int, [C.POINTER(ConvDesc)]),
+    "af_conv_variant_name": (C.c_char_p, [C.c_int]),
     "af_maxpool3d": (C.c_int, [C.POINTER(PoolDesc), C.c_void_p, C.c_void_p, C.c_void_p]),
     "af_avgpool_fc": (C.c_int, [C.POINTER(PoolDesc)] + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 3),
     "af_run_ops": (C.c_int, [C.POINTER(Op), C.c_int, C.c_void_p]),

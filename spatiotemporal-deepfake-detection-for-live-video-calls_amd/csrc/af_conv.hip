@@ -190,11 +190,17 @@ static int launch(const ConvArgs& a, hipStream_t stream) {
     return AF_OK;
 }
 
+// tile variant chosen for a layer (also reported to the caller: af_conv_variant)
+enum { VAR_128x128 = 0, VAR_64x128 = 1 };
+static const char* const kVariantNames[] = {"conv_igemm<BN=128,BM=128>", "conv_igemm<BN=64,BM=128>"};
+
+static int pick_variant(int cout) { return cout % 128 == 0 ? VAR_128x128 : VAR_64x128; }
+
 template <int DT>
 static int dispatch(ConvArgs& a, hipStream_t stream) {
     constexpr int BK = 8 * Elem<DT>::EPC;
     a.kpt = a.Cin / BK;
-    if (a.Cout % 128 == 0) {
+    if (pick_variant(a.Cout) == VAR_128x128) {
         a.tiles_n = a.Cout / 128;
         return launch<DT, 128, 128, 2, 2>(a, stream);
     }
@@ -203,6 +209,15 @@ static int dispatch(ConvArgs& a, hipStream_t stream) {
 }
 
 }  // namespace af
+
+extern "C" int af_conv_variant(const af_conv_desc* d) {
+    AF_REQUIRE(d && d->cout > 0, "conv_variant: bad descriptor");
+    return af::pick_variant(d->cout);
+}
+
+extern "C" const char* af_conv_variant_name(int variant) {
+    return (variant >= 0 && variant < 2) ? af::kVariantNames[variant] : "?";
+}
 
 extern "C" int af_conv3d_bn_act(const af_conv_desc* d, const void* in, const void* w_packed, const float* scale,
                                 const float* shift, const void* residual, void* out, int out_ld, void* stream) {
