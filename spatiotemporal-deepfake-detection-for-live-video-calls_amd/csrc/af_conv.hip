@@ -12,9 +12,13 @@
 //     K-step of one tile row is one contiguous 128-byte run = 8 x 16-byte chunks.
 //   * LDS tiles are [row][8 chunks] with chunk ^= (row & 7): conflict-free ds_write_b128 from the
 //     staging pass and conflict-free ds_read_b128 for the MFMA fragments (bank math in DESIGN.md).
-//   * zero padding is done by predicating the global loads (no halo in HBM).
-//   * pipeline: register-staged double buffering, one barrier per K-step: global loads of step
-//     s+1 are issued before the MFMAs of step s and written to the other LDS buffer after them.
+//   * operands go HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4, 16 B per lane, no VGPR staging and
+//     no ds_write): one wave-instruction fills 8 tile rows; the LDS image is lane-linear, so the
+//     swizzle is applied on the SOURCE side (lane (row, slot) fetches chunk slot ^ (row & 7)).
+//   * zero padding: out-of-bounds taps fetch from a 128-byte zero page instead of the activation
+//     (per-row validity bit per tap, computed once); no halo in HBM, no branch in the K loop.
+//   * pipeline: 3-slot LDS ring, K-steps s+1 and s+2 in flight while step s is multiplied; one raw
+//     s_barrier per K-step; explicit counted s_waitcnt vmcnt (hipcc does not see the DMA loads).
 #include "af_common.h"
 
 namespace af {
@@ -35,21 +39,36 @@ struct ConvArgs {
     int kpt;            // K-steps per tap = Cin / BK
 };
 
-template <int DT, int BN, int BM, int WN, int WM>
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
+// 128 bytes of zeros in HBM: the source of every out-of-bounds (padding) tap, so that zero padding
+// costs no branch and no LDS write of its own - the LDS-DMA simply fetches zeros.
+__device__ uint4 g_zero_page[8];
+
+// one 16-byte-per-lane LDS-DMA: LDS[lds_base + lane*16 .. +16) <- *gsrc (per-lane global address).
+// hipcc does not count this load: every wait on it is an explicit s_waitcnt vmcnt(N) below.
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_base) : "memory");
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// 8 waves (512 threads); wave (wn, wm) owns a (BN/WN) x (BM/WM) sub-tile of 16x16 MFMA tiles.
+template <int DT, int BN, int BM, int WN, int WM, int NSTAGE>
+__global__ __launch_bounds__(512, 2) void conv_igemm_kernel(const ConvArgs a) {
     typedef Elem<DT> E;
     constexpr int EPC = E::EPC;            // elements per 16-byte chunk
     constexpr int ES = 16 / EPC;           // bytes per element
-    constexpr int BK = 8 * EPC;            // K elements per step (128 bytes per tile row)
     constexpr int WTN = BN / WN, WTM = BM / WM;
     constexpr int TN = WTN / 16, TM = WTM / 16;
-    constexpr int RW = BN / 32, RX = BM / 32;   // tile rows staged per thread
-    static_assert(WN * WM == 4, "4 waves per workgroup");
-    static_assert(TN >= 1 && TM >= 1, "tile too small");
+    constexpr int RW = BN / 64, RX = BM / 64;        // tile rows (= LDS-DMA instructions) per thread per stage
+    constexpr int PER_WAVE = RW + RX;                // LDS-DMA instructions a wave issues per stage
+    constexpr int STAGE_BYTES = (BN + BM) * 128;
+    static_assert(WN * WM == 8, "8 waves per workgroup");
+    static_assert(NSTAGE == 3, "the vmcnt bookkeeping below is written for a 3-slot ring");
 
     extern __shared__ uint4 smem[];
-    // buffer b: W tile at smem + b*STAGE, X tile at smem + b*STAGE + BN*8
-    constexpr int STAGE = (BN + BM) * 8;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 
     // ---- workgroup -> tile, XCD-contiguous (bijective remap; placement is a speed matter only)
     const int bid = blockIdx.x, nb = gridDim.x;
@@ -58,63 +77,62 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     const int tile_n = swz % a.tiles_n;
     const int tile_m = swz / a.tiles_n;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave % WN, wm = wave / WN;
-    const int lchunk = tid & 7, lrow = tid >> 3;
+    const int lrow = tid >> 3;                         // 0..63: row inside a 64-row group
+    const int chunk = (tid & 7) ^ (lrow & 7);          // source chunk that lands in LDS slot (tid & 7)
 
-    // ---- per-thread staging rows
+    // ---- per-thread staging rows: global row pointers + a validity bit per tap
+    const int taps = a.kt * a.kh * a.kw;
     const long long m0 = (long long)tile_m * BM;
-    long long xbase[RX];
-    int ti0[RX], hi0[RX], wi0[RX];
+    const char* xptr[RX];
+    unsigned xmask[RX];
 #pragma unroll
     for (int i = 0; i < RX; ++i) {
-        long long m = m0 + lrow + 32 * i;
+        long long m = m0 + lrow + 64 * i;
+        xmask[i] = 0;
+        xptr[i] = a.in;
         if (m < a.M) {
             int wo = (int)(m % a.Wo); long long t1 = m / a.Wo;
             int ho = (int)(t1 % a.Ho); long long t2 = t1 / a.Ho;
             int to = (int)(t2 % a.To); long long n = t2 / a.To;
-            ti0[i] = to * a.st - a.pt; hi0[i] = ho * a.sh - a.ph; wi0[i] = wo * a.sw - a.pw;
-            xbase[i] = (((n * a.T + ti0[i]) * a.H + hi0[i]) * a.W + wi0[i]) * a.Cin + lchunk * EPC;
-        } else {
-            ti0[i] = -(1 << 20); hi0[i] = 0; wi0[i] = 0; xbase[i] = 0;
+            const int ti0 = to * a.st - a.pt, hi0 = ho * a.sh - a.ph, wi0 = wo * a.sw - a.pw;
+            xptr[i] = a.in + ((((n * a.T + ti0) * a.H + hi0) * a.W + wi0) * a.Cin + chunk * EPC) * ES;
+            int tap = 0;
+            for (int dt = 0; dt < a.kt; ++dt)
+                for (int dh = 0; dh < a.kh; ++dh)
+                    for (int dw = 0; dw < a.kw; ++dw, ++tap) {
+                        bool ok = (unsigned)(ti0 + dt) < (unsigned)a.T && (unsigned)(hi0 + dh) < (unsigned)a.H &&
+                                  (unsigned)(wi0 + dw) < (unsigned)a.W;
+                        xmask[i] |= (ok ? 1u : 0u) << tap;
+                    }
         }
     }
-    const int taps = a.kt * a.kh * a.kw;
-    const int Kw = taps * a.Cin;               // weight row length (elements)
-    int wbase[RW];
+    const long long Kw = (long long)taps * a.Cin;      // weight row length (elements)
+    const char* wptr[RW];
 #pragma unroll
-    for (int i = 0; i < RW; ++i) wbase[i] = (tile_n * BN + lrow + 32 * i) * Kw + lchunk * EPC;
+    for (int i = 0; i < RW; ++i) wptr[i] = a.w + ((tile_n * BN + lrow + 64 * i) * Kw + chunk * EPC) * ES;
+    const char* zero = reinterpret_cast<const char*>(g_zero_page);
 
-    uint4 xr[RX], wr[RW];
-    int dt = 0, dh = 0, dw = 0, kc = 0, tap = 0;   // position of the NEXT step to load
-
-    auto load_step = [&]() {
-        const long long tapoff = ((long long)(dt * a.H + dh) * a.W + dw) * a.Cin + kc * BK;
+    // ---- LDS-DMA producer: stage `st` <- K-step (tap, kc); counters walk kc fastest, then dw, dh, dt
+    int dt = 0, dh = 0, dw = 0, kc = 0, tap = 0, kstep = 0;
+    auto issue_stage = [&](int st) {
+        const unsigned base = lds0 + st * STAGE_BYTES + wave * (8 * 128);
+        const long long woff = (long long)kstep * 128;
+        const long long xoff = ((long long)(dt * a.H + dh) * a.W + dw) * a.Cin * ES + kc * 128;
+#pragma unroll
+        for (int i = 0; i < RW; ++i) glds16(wptr[i] + woff, base + i * (64 * 128));
 #pragma unroll
         for (int i = 0; i < RX; ++i) {
-            bool ok = (unsigned)(ti0[i] + dt) < (unsigned)a.T && (unsigned)(hi0[i] + dh) < (unsigned)a.H &&
-                      (unsigned)(wi0[i] + dw) < (unsigned)a.W;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (ok) v = *reinterpret_cast<const uint4*>(a.in + (xbase[i] + tapoff) * ES);
-            xr[i] = v;
+            const char* src = ((xmask[i] >> tap) & 1u) ? xptr[i] + xoff : zero;
+            glds16(src, base + (RW + i) * (64 * 128));
         }
-        const int woff = tap * a.Cin + kc * BK;
-#pragma unroll
-        for (int i = 0; i < RW; ++i) wr[i] = *reinterpret_cast<const uint4*>(a.w + (long long)(wbase[i] + woff) * ES);
-        // advance (kc fastest, then dw, dh, dt)
+        ++kstep;
         if (++kc == a.kpt) {
             kc = 0; ++tap;
             if (++dw == a.kw) { dw = 0; if (++dh == a.kh) { dh = 0; ++dt; } }
         }
-    };
-    auto store_lds = [&](int buf) {
-        uint4* ws = smem + buf * STAGE;
-        uint4* xs = ws + BN * 8;
-        const int sw_ = lchunk ^ (lrow & 7);
-#pragma unroll
-        for (int i = 0; i < RW; ++i) ws[(lrow + 32 * i) * 8 + sw_] = wr[i];
-#pragma unroll
-        for (int i = 0; i < RX; ++i) xs[(lrow + 32 * i) * 8 + sw_] = xr[i];
     };
 
     f32x4 acc[TN][TM];
@@ -124,16 +142,19 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
         for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int S = taps * a.kpt;
-    load_step();
-    store_lds(0);
-    __syncthreads();
+    issue_stage(0);
+    if (S > 1) issue_stage(1);
 
     const int frow = lane & 15, fg = lane >> 4;
+    int st = 0;
     for (int s = 0; s < S; ++s) {
-        const int buf = s & 1;
-        if (s + 1 < S) load_step();
-        const uint4* ws = smem + buf * STAGE + (wn * WTN + frow) * 8;
-        const uint4* xs = smem + buf * STAGE + BN * 8 + (wm * WTM + frow) * 8;
+        // stage s has landed for this wave once only the younger stage (s+1) is still in flight ...
+        if (s + 1 < S) wait_vmcnt<PER_WAVE>(); else wait_vmcnt<0>();
+        // ... and for every wave after the barrier, which also retires all reads of slot (s-1)%3
+        __builtin_amdgcn_s_barrier();
+        if (s + 2 < S) issue_stage(st == 0 ? 2 : st - 1);          // refill slot (s+2)%3 == (s-1)%3
+        const uint4* ws = smem + st * (STAGE_BYTES / 16) + (wn * WTN + frow) * 8;
+        const uint4* xs = smem + st * (STAGE_BYTES / 16) + BN * 8 + (wm * WTM + frow) * 8;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int c = (kk * 4 + fg) ^ (frow & 7);
@@ -147,8 +168,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
                 for (int j = 0; j < TM; ++j) Mma<DT>::run(af[i], bf[j], acc[i][j]);
         }
-        if (s + 1 < S) store_lds(buf ^ 1);
-        __syncthreads();
+        st = (st == 2) ? 0 : st + 1;
     }
 
     // ---- epilogue: BN scale/shift (+ residual) (+ ReLU), 4 consecutive channels per lane
@@ -174,38 +194,39 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
 
 template <int DT, int BN, int BM, int WN, int WM>
 static int launch(const ConvArgs& a, hipStream_t stream) {
+    constexpr int NSTAGE = 3;
     const long long tiles_m = (a.M + BM - 1) / BM;
     const long long blocks = tiles_m * a.tiles_n;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return set_error(AF_ERR_ARG, "conv: grid of %lld workgroups", blocks);
-    constexpr int lds = 2 * (BN + BM) * 128;
+    constexpr int lds = NSTAGE * (BN + BM) * 128;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<DT, BN, BM, WN, WM>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<DT, BN, BM, WN, WM, NSTAGE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return set_error(AF_ERR_LAUNCH, "conv: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_igemm_kernel<DT, BN, BM, WN, WM>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<DT, BN, BM, WN, WM, NSTAGE>), dim3((unsigned)blocks), dim3(512), lds, stream, a);
     AF_CHECK_LAUNCH("conv_igemm_kernel");
     return AF_OK;
 }
 
 // tile variant chosen for a layer (also reported to the caller: af_conv_variant)
-enum { VAR_128x128 = 0, VAR_64x128 = 1 };
-static const char* const kVariantNames[] = {"conv_igemm<BN=128,BM=128>", "conv_igemm<BN=64,BM=128>"};
+enum { VAR_128x256 = 0, VAR_64x256 = 1 };
+static const char* const kVariantNames[] = {"conv_igemm<BN=128,BM=256>", "conv_igemm<BN=64,BM=256>"};
 
-static int pick_variant(int cout) { return cout % 128 == 0 ? VAR_128x128 : VAR_64x128; }
+static int pick_variant(int cout) { return cout % 128 == 0 ? VAR_128x256 : VAR_64x256; }
 
 template <int DT>
 static int dispatch(ConvArgs& a, hipStream_t stream) {
     constexpr int BK = 8 * Elem<DT>::EPC;
     a.kpt = a.Cin / BK;
-    if (pick_variant(a.Cout) == VAR_128x128) {
+    if (pick_variant(a.Cout) == VAR_128x256) {
         a.tiles_n = a.Cout / 128;
-        return launch<DT, 128, 128, 2, 2>(a, stream);
+        return launch<DT, 128, 256, 2, 4>(a, stream);
     }
     a.tiles_n = a.Cout / 64;
-    return launch<DT, 64, 128, 2, 2>(a, stream);
+    return launch<DT, 64, 256, 1, 8>(a, stream);
 }
 
 }  // namespace af
@@ -239,6 +260,7 @@ extern "C" int af_conv3d_bn_act(const af_conv_desc* d, const void* in, const voi
     AF_REQUIRE(aligned16(in) && aligned16(w_packed) && aligned16(scale) && aligned16(shift) && aligned16(out) &&
                    aligned16(residual), "conv: buffers must be 16-byte aligned");
     AF_REQUIRE((long long)d->cout * d->kt * d->kh * d->kw * d->cin < (1LL << 31), "conv: weight too large");
+    AF_REQUIRE(d->kt * d->kh * d->kw <= 32, "conv: at most 32 kernel taps (got %d)", d->kt * d->kh * d->kw);
 
     ConvArgs a;
     a.in = (const char*)in; a.w = (const char*)w_packed; a.scale = scale; a.shift = shift;
