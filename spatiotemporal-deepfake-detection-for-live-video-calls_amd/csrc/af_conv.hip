@@ -6,8 +6,8 @@
 // GEMM view:  D[cout][pos] = sum_k  Wp[cout][k] * X[pos][k],   k = (tap, cin),  pos = (n,to,ho,wo)
 //   * weights are the MFMA "A" operand (rows = output channels) and im2col'ed activations the "B"
 //     operand (cols = output positions): the 16x16 accumulator then holds 4 CONSECUTIVE CHANNELS
-//     of one position per lane, so the epilogue reads scale/shift/residual and writes NDHWC with
-//     16-byte (fp32) / 8-byte (16-bit) vector accesses and no transpose.
+//     of one position per lane, so BN scale/shift are per-lane vectors; a per-wave LDS patch then
+//     turns the sub-tile into whole NDHWC rows (16 B per lane, full 128-byte lines).
 //   * both operands are K-contiguous in memory ([cout][tap][cin] weights, NDHWC activations), so a
 //     K-step of one tile row is one contiguous 128-byte run = 8 x 16-byte chunks.
 //   * LDS tiles are [row][8 chunks] with chunk ^= (row & 7): conflict-free ds_write_b128 from the
@@ -54,8 +54,8 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_base) {
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // 8 waves (512 threads); wave (wn, wm) owns a (BN/WN) x (BM/WM) sub-tile of 16x16 MFMA tiles.
-template <int DT, int BN, int BM, int WN, int WM, int NSTAGE>
-__global__ __launch_bounds__(512, 2) void conv_igemm_kernel(const ConvArgs a) {
+template <int DT, int BN, int BM, int WN, int WM, int NSTAGE, int MINW>
+__global__ __launch_bounds__(512, MINW) void conv_igemm_kernel(const ConvArgs a) {
     typedef Elem<DT> E;
     constexpr int EPC = E::EPC;            // elements per 16-byte chunk
     constexpr int ES = 16 / EPC;           // bytes per element
@@ -171,73 +171,126 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_kernel(const ConvArgs a) {
         st = (st == 2) ? 0 : st + 1;
     }
 
-    // ---- epilogue: BN scale/shift (+ residual) (+ ReLU), 4 consecutive channels per lane
+    // ---- epilogue.  The MFMA accumulator holds 4 consecutive channels of one position per lane: fine for
+    // the per-channel BN scale/shift, too narrow for HBM (8-byte pieces of a line).  Each wave therefore
+    // transposes its sub-tile through a private fp32 LDS patch ([position][WTN + 4 pad] floats; the ring is
+    // dead by now) and then streams whole rows: 16 bytes per lane, full 128-byte lines per row for the
+    // output store AND the residual load.  Residual add and ReLU happen in fp32 before the one rounding.
+    __builtin_amdgcn_s_barrier();                      // every wave has finished reading the ring
+    constexpr int PROW = WTN + 4;                      // patch row stride in floats (pad: conflict-free b128 writes)
+    constexpr int HALVES = TM >= 2 ? 2 : 1;            // the patch holds half the sub-tile at a time (LDS footprint)
+    constexpr int TMH = TM / HALVES, PROWS = TMH * 16;
+    float* patch = reinterpret_cast<float*>(smem) + wave * (PROWS * PROW);
+    constexpr int LPR = WTN / EPC;                     // lanes per output row (16 bytes each)
+    constexpr int RPI = 64 / LPR;                      // rows per wave-instruction
+    const int rr = lane / LPR, cc = (lane % LPR) * EPC;
+    const int ch0 = tile_n * BN + wn * WTN + cc;
 #pragma unroll
-    for (int i = 0; i < TN; ++i) {
-        const int ch = tile_n * BN + wn * WTN + i * 16 + fg * 4;
-        const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + ch);
-        const f32x4 sf = *reinterpret_cast<const f32x4*>(a.shift + ch);
+    for (int hf = 0; hf < HALVES; ++hf) {
 #pragma unroll
-        for (int j = 0; j < TM; ++j) {
-            const long long m = m0 + wm * WTM + j * 16 + frow;
+        for (int i = 0; i < TN; ++i) {
+            const int chl = i * 16 + fg * 4;           // channel inside the wave's sub-tile
+            const int ch = tile_n * BN + wn * WTN + chl;
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + ch);
+            const f32x4 sf = *reinterpret_cast<const f32x4*>(a.shift + ch);
+#pragma unroll
+            for (int j = 0; j < TMH; ++j)
+                *reinterpret_cast<f32x4*>(patch + (j * 16 + frow) * PROW + chl) = acc[i][hf * TMH + j] * sc + sf;
+        }
+        __builtin_amdgcn_wave_barrier();               // same-wave LDS ops complete in order; keep the order
+#pragma unroll
+        for (int it = 0; it < PROWS / RPI; ++it) {
+            const int row = it * RPI + rr;
+            const long long m = m0 + wm * WTM + hf * PROWS + row;
+            float v[EPC];
+#pragma unroll
+            for (int e = 0; e < EPC; e += 4) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(patch + row * PROW + cc + e);
+                v[e] = t[0]; v[e + 1] = t[1]; v[e + 2] = t[2]; v[e + 3] = t[3];
+            }
             if (m < a.M) {
-                f32x4 v = acc[i][j] * sc + sf;
-                if (a.res) v += Vec4<DT>::load(a.res + (m * a.Cout + ch) * ES);
-                if (a.relu) {
-                    v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+                if (a.res) {
+                    const uint4 rraw = *reinterpret_cast<const uint4*>(a.res + (m * a.Cout + ch0) * ES);
+                    const typename E::type* re = reinterpret_cast<const typename E::type*>(&rraw);
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) v[e] += E::to_f32(re[e]);
                 }
-                Vec4<DT>::store(a.out + (m * a.out_ld + ch) * ES, v);
+                if (a.relu) {
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                uint4 o;
+                typename E::type* oe = reinterpret_cast<typename E::type*>(&o);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) oe[e] = E::from_f32(v[e]);
+                *reinterpret_cast<uint4*>(a.out + (m * a.out_ld + ch0) * ES) = o;
             }
         }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
-template <int DT, int BN, int BM, int WN, int WM>
+template <int DT, int BN, int BM, int WN, int WM, int MINW>
 static int launch(const ConvArgs& a, hipStream_t stream) {
     constexpr int NSTAGE = 3;
     const long long tiles_m = (a.M + BM - 1) / BM;
     const long long blocks = tiles_m * a.tiles_n;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return set_error(AF_ERR_ARG, "conv: grid of %lld workgroups", blocks);
-    constexpr int lds = NSTAGE * (BN + BM) * 128;
+    // LDS actually needed: the ring slots this layer's K loop touches, or the epilogue patches
+    constexpr int TMv = BM / WM / 16;
+    constexpr int patch_bytes = 8 * ((TMv >= 2 ? TMv / 2 : TMv) * 16) * (BN / WN + 4) * 4;
+    const int S = a.kt * a.kh * a.kw * a.kpt;
+    const int ring_bytes = (S < NSTAGE ? S : NSTAGE) * (BN + BM) * 128;
+    const int lds = ring_bytes > patch_bytes ? ring_bytes : patch_bytes;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<DT, BN, BM, WN, WM, NSTAGE>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<DT, BN, BM, WN, WM, NSTAGE, MINW>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE * (BN + BM) * 128);
         if (e != hipSuccess) return set_error(AF_ERR_LAUNCH, "conv: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_igemm_kernel<DT, BN, BM, WN, WM, NSTAGE>), dim3((unsigned)blocks), dim3(512), lds, stream, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<DT, BN, BM, WN, WM, NSTAGE, MINW>), dim3((unsigned)blocks), dim3(512), lds, stream, a);
     AF_CHECK_LAUNCH("conv_igemm_kernel");
     return AF_OK;
 }
 
-// tile variant chosen for a layer (also reported to the caller: af_conv_variant)
-enum { VAR_128x256 = 0, VAR_64x256 = 1 };
-static const char* const kVariantNames[] = {"conv_igemm<BN=128,BM=256>", "conv_igemm<BN=64,BM=256>"};
+// tile variant chosen for a layer (also reported to the caller: af_conv_variant).  Long-K layers are
+// MFMA-bound: biggest tile.  Short-K layers (<= 4 K-steps) are HBM-bound streams of input, residual and
+// output: half-height tiles with a trimmed ring so several workgroups share a CU and overlap each
+// other's load / store phases.
+enum { VAR_128x256 = 0, VAR_64x256 = 1, VAR_128x128 = 2, VAR_64x128 = 3, VAR_COUNT = 4 };
+static const char* const kVariantNames[] = {"conv_igemm<BN=128,BM=256>", "conv_igemm<BN=64,BM=256>",
+                                            "conv_igemm<BN=128,BM=128>", "conv_igemm<BN=64,BM=128>"};
 
-static int pick_variant(int cout) { return cout % 128 == 0 ? VAR_128x256 : VAR_64x256; }
+static int pick_variant(int cout, int cin, int taps, int dtype) {
+    const int ksteps = taps * (cin / (dtype == AF_F32 ? 32 : 64));
+    const bool wide = cout % 128 == 0, short_k = ksteps <= 4;
+    return wide ? (short_k ? VAR_128x128 : VAR_128x256) : (short_k ? VAR_64x128 : VAR_64x256);
+}
 
 template <int DT>
 static int dispatch(ConvArgs& a, hipStream_t stream) {
     constexpr int BK = 8 * Elem<DT>::EPC;
     a.kpt = a.Cin / BK;
-    if (pick_variant(a.Cout) == VAR_128x256) {
-        a.tiles_n = a.Cout / 128;
-        return launch<DT, 128, 256, 2, 4>(a, stream);
+    const int v = pick_variant(a.Cout, a.Cin, a.kt * a.kh * a.kw, DT);
+    a.tiles_n = a.Cout / ((v == VAR_128x256 || v == VAR_128x128) ? 128 : 64);
+    switch (v) {
+        case VAR_128x256: return launch<DT, 128, 256, 2, 4, 2>(a, stream);
+        case VAR_64x256: return launch<DT, 64, 256, 1, 8, 2>(a, stream);
+        case VAR_128x128: return launch<DT, 128, 128, 2, 4, 4>(a, stream);
+        default: return launch<DT, 64, 128, 1, 8, 4>(a, stream);
     }
-    a.tiles_n = a.Cout / 64;
-    return launch<DT, 64, 256, 1, 8>(a, stream);
 }
 
 }  // namespace af
 
 extern "C" int af_conv_variant(const af_conv_desc* d) {
-    AF_REQUIRE(d && d->cout > 0, "conv_variant: bad descriptor");
-    return af::pick_variant(d->cout);
+    AF_REQUIRE(d && d->cout > 0 && d->cin > 0 && af::dtype_ok(d->dtype), "conv_variant: bad descriptor");
+    return af::pick_variant(d->cout, d->cin, d->kt * d->kh * d->kw, d->dtype);
 }
 
 extern "C" const char* af_conv_variant_name(int variant) {
-    return (variant >= 0 && variant < 2) ? af::kVariantNames[variant] : "?";
+    return (variant >= 0 && variant < af::VAR_COUNT) ? af::kVariantNames[variant] : "?";
 }
 
 extern "C" int af_conv3d_bn_act(const af_conv_desc* d, const void* in, const void* w_packed, const float* scale,
@@ -256,7 +309,7 @@ extern "C" int af_conv3d_bn_act(const af_conv_desc* d, const void* in, const voi
     AF_REQUIRE(d->cin % bk == 0, "conv: cin=%d must be a multiple of %d for this dtype", d->cin, bk);
     AF_REQUIRE(d->cout % 64 == 0, "conv: cout=%d must be a multiple of 64", d->cout);
     if (out_ld == 0) out_ld = d->cout;
-    AF_REQUIRE(out_ld >= d->cout && out_ld % 4 == 0, "conv: bad out_ld %d", out_ld);
+    AF_REQUIRE(out_ld >= d->cout && out_ld % 8 == 0, "conv: bad out_ld %d", out_ld);
     AF_REQUIRE(aligned16(in) && aligned16(w_packed) && aligned16(scale) && aligned16(shift) && aligned16(out) &&
                    aligned16(residual), "conv: buffers must be 16-byte aligned");
     AF_REQUIRE((long long)d->cout * d->kt * d->kh * d->kw * d->cin < (1LL << 31), "conv: weight too large");
