@@ -255,7 +255,7 @@ static int launch(const ConvArgs& a, hipStream_t stream) {
 }
 
 // tile variant chosen for a layer (also reported to the caller: af_conv_variant).  Long-K layers are
-// MFMA-bound: biggest tile.  Short-K layers (<= 4 K-steps) are HBM-bound streams of input, residual and
+// MFMA-bound: biggest tile.  Short-K layers (<= 3 K-steps) are HBM-bound streams of input, residual and
 // output: half-height tiles with a trimmed ring so several workgroups share a CU and overlap each
 // other's load / store phases.
 enum { VAR_128x256 = 0, VAR_64x256 = 1, VAR_128x128 = 2, VAR_64x128 = 3, VAR_COUNT = 4 };
@@ -264,7 +264,7 @@ static const char* const kVariantNames[] = {"conv_igemm<BN=128,BM=256>", "conv_i
 
 static int pick_variant(int cout, int cin, int taps, int dtype) {
     const int ksteps = taps * (cin / (dtype == AF_F32 ? 32 : 64));
-    const bool wide = cout % 128 == 0, short_k = ksteps <= 4;
+    const bool wide = cout % 128 == 0, short_k = ksteps <= 3;
     return wide ? (short_k ? VAR_128x128 : VAR_128x256) : (short_k ? VAR_64x128 : VAR_64x256);
 }
 

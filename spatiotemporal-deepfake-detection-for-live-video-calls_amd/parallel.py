@@ -52,7 +52,11 @@ def gather_logits(local_logits: torch.Tensor, global_batch: int, out: torch.Tens
             out = torch.empty((global_batch, k), dtype=local_logits.dtype, device=local_logits.device)
         dist.all_gather_into_tensor(out, local_logits.contiguous())
         return out
-    per = [torch.empty((shard_bounds(global_batch, r, world)[1] - shard_bounds(global_batch, r, world)[0], k),
-                       dtype=local_logits.dtype, device=local_logits.device) for r in range(world)]
-    dist.all_gather(per, local_logits.contiguous())
-    return torch.cat(per, 0)
+    # ragged shards: pad every rank's block to the largest shard, gather, trim (collectives need equal sizes)
+    counts = [shard_bounds(global_batch, r, world)[1] - shard_bounds(global_batch, r, world)[0] for r in range(world)]
+    cmax = max(counts)
+    padded = torch.zeros((cmax, k), dtype=local_logits.dtype, device=local_logits.device)
+    padded[:local_logits.shape[0]] = local_logits
+    allp = torch.empty((world * cmax, k), dtype=local_logits.dtype, device=local_logits.device)
+    dist.all_gather_into_tensor(allp, padded)
+    return torch.cat([allp[r * cmax:r * cmax + counts[r]] for r in range(world)], 0)
