@@ -48,6 +48,24 @@ def cpu_baseline(sd, u8, threads_all):
                            "1 clip on 1 thread: %.3f clips/s" % (x.shape[0], threads_all, 1.0 / t_one)}
 
 
+def pmc_traffic(kernel_label, dtype):
+    """HBM bytes per launch of the roofline kernel from the committed rocprofv3 PMC passes of this same command
+    (profiles/*_<dtype>_traffic.json, written by tools/summarize_profile.py); None if no such profile exists."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_%s_traffic.json" % dtype)))
+    if not files:
+        return None, None
+    m = re.search(r"BN=(\d+),BM=(\d+)", kernel_label)
+    data = json.load(open(files[-1]))["kernels"]
+    for name, v in data.items():
+        if m and re.search(r"conv_igemm_kernel<\d+, %s, %s," % (m.group(1), m.group(2)), name):
+            return v["hbm_bytes_per_launch"], os.path.relpath(files[-1], ROOT)
+        if not m and kernel_label in name:
+            return v["hbm_bytes_per_launch"], os.path.relpath(files[-1], ROOT)
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -129,8 +147,15 @@ def main():
             ms = [a / reps for a in acc]
             # per kernel instantiation (conv variants) and per layer class
             per_kernel, per_class = {}, {}
+            es = 4 if args.dtype == "f32" else 2
+            eng_bytes, kernel_ops = {}, {}
             for i in range(eng.n_ops):
                 op = eng.ops[i]
+                if op.kind in (_lib.AF_OP_CONV, _lib.AF_OP_STEM):
+                    cd = op.conv
+                    mm = cd.n * cd.to * cd.ho * cd.wo
+                    eng_bytes[i] = es * (cd.n * cd.t * cd.h * cd.w * cd.cin + mm * cd.cout * (2 if op.residual else 1)
+                                         + cd.cout * cd.cin * cd.kt * cd.kh * cd.kw)
                 cls = TAG_NAMES[op.tag]
                 c = per_class.setdefault(cls, {"ms": 0.0, "macs": 0, "launches": 0})
                 c["ms"] += ms[i]; c["macs"] += eng.op_macs[i]; c["launches"] += 1
@@ -143,6 +168,7 @@ def main():
                     continue
                 k = per_kernel.setdefault(kname, {"ms": 0.0, "macs": 0, "launches": 0})
                 k["ms"] += ms[i]; k["macs"] += eng.op_macs[i]; k["launches"] += 1
+                kernel_ops.setdefault(kname, []).append(i)
             if args.layers_json:
                 es = 4 if args.dtype == "f32" else 2
                 rows = []
@@ -162,6 +188,7 @@ def main():
                     json.dump(rows, f, indent=0)
             dom = max(per_kernel, key=lambda k: per_kernel[k]["ms"])
             d = per_kernel[dom]
+            dom_ops = kernel_ops[dom]
             achieved = 2 * d["macs"] / (d["ms"] * 1e-3) / 1e12
             line["roofline"] = {
                 "bound": "mfma", "kernel": dom, "launches_per_step": d["launches"],
@@ -170,6 +197,12 @@ def main():
                 "achieved": round(achieved, 2), "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_TFLOPS[args.dtype], 4), "traffic": None,
             }
+            tr, src = pmc_traffic(dom, args.dtype)
+            if tr is not None:
+                line["roofline"]["traffic"] = round(tr)
+                line["roofline"]["traffic_unit"] = "HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE), " + src
+                alg_bytes = sum(eng_bytes[i] for i in dom_ops) / max(len(dom_ops), 1)
+                line["roofline"]["algorithmic_bytes_per_launch"] = round(alg_bytes)
             line["device_ms_per_step"] = round(sum(ms), 3)
             line["classes"] = {k: {"ms": round(v["ms"], 3), "launches": v["launches"],
                                    "tflops": round(2 * v["macs"] / max(v["ms"], 1e-9) / 1e9, 1) if v["macs"] else None}

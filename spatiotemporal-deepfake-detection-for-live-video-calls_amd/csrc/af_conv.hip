@@ -54,7 +54,9 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_base) {
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // 8 waves (512 threads); wave (wn, wm) owns a (BN/WN) x (BM/WM) sub-tile of 16x16 MFMA tiles.
-template <int DT, int BN, int BM, int WN, int WM, int NSTAGE, int MINW>
+// KS = 2 splits each stage's K between wave groups 0-3 / 4-7 (used for Cout = 64: every wave then owns a
+// 64x64 sub-tile, halving LDS fragment traffic per MFMA; the two partial sums meet in LDS after the loop).
+template <int DT, int BN, int BM, int WN, int WM, int KS, int NSTAGE, int MINW>
 __global__ __launch_bounds__(512, MINW) void conv_igemm_kernel(const ConvArgs a) {
     typedef Elem<DT> E;
     constexpr int EPC = E::EPC;            // elements per 16-byte chunk
@@ -64,7 +66,8 @@ __global__ __launch_bounds__(512, MINW) void conv_igemm_kernel(const ConvArgs a)
     constexpr int RW = BN / 64, RX = BM / 64;        // tile rows (= LDS-DMA instructions) per thread per stage
     constexpr int PER_WAVE = RW + RX;                // LDS-DMA instructions a wave issues per stage
     constexpr int STAGE_BYTES = (BN + BM) * 128;
-    static_assert(WN * WM == 8, "8 waves per workgroup");
+    static_assert(WN * WM * KS == 8 && (KS == 1 || KS == 2), "8 waves per workgroup");
+    constexpr bool LEAN = MINW >= 4;
     static_assert(NSTAGE == 3, "the vmcnt bookkeeping below is written for a 3-slot ring");
 
     extern __shared__ uint4 smem[];
@@ -79,7 +82,8 @@ __global__ __launch_bounds__(512, MINW) void conv_igemm_kernel(const ConvArgs a)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn = wave % WN, wm = wave / WN;
+    const int kgroup = wave / (WN * WM), wsub = wave % (WN * WM);
+    const int wn = wsub % WN, wm = wsub / WN;
     const int lrow = tid >> 3;                         // 0..63: row inside a 64-row group
     const int chunk = (tid & 7) ^ (lrow & 7);          // source chunk that lands in LDS slot (tid & 7)
 
@@ -115,24 +119,37 @@ __global__ __launch_bounds__(512, MINW) void conv_igemm_kernel(const ConvArgs a)
     for (int i = 0; i < RW; ++i) wptr[i] = a.w + ((tile_n * BN + lrow + 64 * i) * Kw + chunk * EPC) * ES;
     const char* zero = reinterpret_cast<const char*>(g_zero_page);
 
-    // ---- LDS-DMA producer: stage `st` <- K-step (tap, kc); counters walk kc fastest, then dw, dh, dt
-    int dt = 0, dh = 0, dw = 0, kc = 0, tap = 0, kstep = 0;
+    // ---- LDS-DMA producer: stage `st` <- K-step (kc, tap).  The TAPS are the inner loop: for one 64-channel
+    // slab the kT*kH*kW shifted copies of the tile's rows are fetched back to back, so a row fetched for tap
+    // (dh,dw) is re-read for its neighbours while it is still in L1/L2 (reuse distance ~ one slab, 32 KB per
+    // workgroup) instead of after a sweep over all of Cin (which thrashed the 4 MiB L2 of the XCD).
+    // A stage is PER_WAVE pieces per wave (weights rows first, then activation rows); pieces can be issued one
+    // at a time so that the main loop can tuck them between MFMA groups.
+    int dt = 0, dh = 0, dw = 0, kc = 0, tap = 0;
+    auto issue_piece = [&](int st, int g) {
+        const unsigned base = lds0 + st * STAGE_BYTES + wave * (8 * 128) + g * (64 * 128);
+        if (g < RW) {
+            glds16(wptr[g] + (long long)(tap * a.Cin * ES + kc * 128), base);
+        } else {
+            const int xoff = ((dt * a.H + dh) * a.W + dw) * a.Cin * ES + kc * 128;   // < 2^31 (host-checked)
+            const char* src = ((xmask[g - RW] >> tap) & 1u) ? xptr[g - RW] + xoff : zero;
+            glds16(src, base);
+        }
+    };
+    auto advance = [&]() {
+        ++tap;
+        if (++dw == a.kw) {
+            dw = 0;
+            if (++dh == a.kh) {
+                dh = 0;
+                if (++dt == a.kt) { dt = 0; tap = 0; ++kc; }
+            }
+        }
+    };
     auto issue_stage = [&](int st) {
-        const unsigned base = lds0 + st * STAGE_BYTES + wave * (8 * 128);
-        const long long woff = (long long)kstep * 128;
-        const long long xoff = ((long long)(dt * a.H + dh) * a.W + dw) * a.Cin * ES + kc * 128;
 #pragma unroll
-        for (int i = 0; i < RW; ++i) glds16(wptr[i] + woff, base + i * (64 * 128));
-#pragma unroll
-        for (int i = 0; i < RX; ++i) {
-            const char* src = ((xmask[i] >> tap) & 1u) ? xptr[i] + xoff : zero;
-            glds16(src, base + (RW + i) * (64 * 128));
-        }
-        ++kstep;
-        if (++kc == a.kpt) {
-            kc = 0; ++tap;
-            if (++dw == a.kw) { dw = 0; if (++dh == a.kh) { dh = 0; ++dt; } }
-        }
+        for (int g = 0; g < PER_WAVE; ++g) issue_piece(st, g);
+        advance();
     };
 
     f32x4 acc[TN][TM];
@@ -146,27 +163,67 @@ __global__ __launch_bounds__(512, MINW) void conv_igemm_kernel(const ConvArgs a)
     if (S > 1) issue_stage(1);
 
     const int frow = lane & 15, fg = lane >> 4;
+    constexpr int NKK = 2 / KS;                                   // k-halves of a stage this wave multiplies
+    constexpr int NT = NKK * TN * TM;                             // 16x16 tile products per stage per wave
+    const int kk0 = KS == 2 ? kgroup : 0;
     int st = 0;
     for (int s = 0; s < S; ++s) {
         // stage s has landed for this wave once only the younger stage (s+1) is still in flight ...
         if (s + 1 < S) wait_vmcnt<PER_WAVE>(); else wait_vmcnt<0>();
         // ... and for every wave after the barrier, which also retires all reads of slot (s-1)%3
         __builtin_amdgcn_s_barrier();
-        if (s + 2 < S) issue_stage(st == 0 ? 2 : st - 1);          // refill slot (s+2)%3 == (s-1)%3
+        const bool refill = s + 2 < S;                            // slot (s+2)%3 == (s-1)%3 is free now
+        const int nst = st == 0 ? 2 : st - 1;
         const uint4* ws = smem + st * (STAGE_BYTES / 16) + (wn * WTN + frow) * 8;
         const uint4* xs = smem + st * (STAGE_BYTES / 16) + BN * 8 + (wm * WTM + frow) * 8;
+        if (LEAN) {
+            // HBM-bound short-K variants: smallest register footprint (more workgroups per CU)
+            if (refill) issue_stage(nst);
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const int c = (kk * 4 + fg) ^ (frow & 7);
-            uint4 af[TN], bf[TM];
+            for (int q = 0; q < NKK; ++q) {
+                const int c = ((kk0 + q) * 4 + fg) ^ (frow & 7);
+                uint4 af[TN], bf[TM];
 #pragma unroll
-            for (int i = 0; i < TN; ++i) af[i] = ws[i * 16 * 8 + c];
+                for (int i = 0; i < TN; ++i) af[i] = ws[i * 16 * 8 + c];
 #pragma unroll
-            for (int j = 0; j < TM; ++j) bf[j] = xs[j * 16 * 8 + c];
+                for (int j = 0; j < TM; ++j) bf[j] = xs[j * 16 * 8 + c];
 #pragma unroll
-            for (int i = 0; i < TN; ++i)
+                for (int i = 0; i < TN; ++i)
 #pragma unroll
-                for (int j = 0; j < TM; ++j) Mma<DT>::run(af[i], bf[j], acc[i][j]);
+                    for (int j = 0; j < TM; ++j) Mma<DT>::run(af[i], bf[j], acc[i][j]);
+            }
+        } else {
+            // MFMA-bound variants: all fragment reads of the stage go out first; then the LDS-DMA pieces of stage
+            // s+2 (SALU m0 juggling + address VALU + a ~60-cycle VMEM issue each) are tucked BETWEEN groups of
+            // MFMAs, so the matrix pipe keeps running under them (and under the partner wave's) instead of idling
+            // through a load-issue phase after every barrier.  sched_barrier pins the interleave.
+            uint4 af[NKK][TN], bf[NKK][TM];
+#pragma unroll
+            for (int q = 0; q < NKK; ++q) {
+                const int c = ((kk0 + q) * 4 + fg) ^ (frow & 7);
+#pragma unroll
+                for (int i = 0; i < TN; ++i) af[q][i] = ws[i * 16 * 8 + c];
+#pragma unroll
+                for (int j = 0; j < TM; ++j) bf[q][j] = xs[j * 16 * 8 + c];
+            }
+            constexpr int MPG = NT / (PER_WAVE + 1);              // tile products between two pieces
+#pragma unroll
+            for (int g = 0; g <= PER_WAVE; ++g) {
+                if (g < PER_WAVE) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (refill) issue_piece(nst, g);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                const int lo = g * MPG, hi = (g == PER_WAVE) ? NT : (g + 1) * MPG;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    if (t >= lo && t < hi) {
+                        const int q = t / (TN * TM), i = (t % (TN * TM)) / TM, j = t % TM;
+                        Mma<DT>::run(af[q][i], bf[q][j], acc[i][j]);
+                    }
+                }
+            }
+            if (refill) advance();
         }
         st = (st == 2) ? 0 : st + 1;
     }
@@ -177,10 +234,28 @@ __global__ __launch_bounds__(512, MINW) void conv_igemm_kernel(const ConvArgs a)
     // dead by now) and then streams whole rows: 16 bytes per lane, full 128-byte lines per row for the
     // output store AND the residual load.  Residual add and ReLU happen in fp32 before the one rounding.
     __builtin_amdgcn_s_barrier();                      // every wave has finished reading the ring
+    int patch_off = 0;                                 // floats
+    if (KS == 2) {
+        // K-split partners: waves 4-7 park their partial sums in LDS (lane-linear, conflict-free), waves 0-3 add them
+        f32x4* red = reinterpret_cast<f32x4*>(smem);
+        if (kgroup == 1) {
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j) red[(wsub * TN * TM + i * TM + j) * 64 + lane] = acc[i][j];
+        }
+        __builtin_amdgcn_s_barrier();
+        if (kgroup == 1) return;
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j) acc[i][j] += red[(wsub * TN * TM + i * TM + j) * 64 + lane];
+        patch_off = WN * WM * TN * TM * 64 * 4;        // patches live above the reduction buffer
+    }
     constexpr int PROW = WTN + 4;                      // patch row stride in floats (pad: conflict-free b128 writes)
     constexpr int HALVES = TM >= 2 ? 2 : 1;            // the patch holds half the sub-tile at a time (LDS footprint)
     constexpr int TMH = TM / HALVES, PROWS = TMH * 16;
-    float* patch = reinterpret_cast<float*>(smem) + wave * (PROWS * PROW);
+    float* patch = reinterpret_cast<float*>(smem) + patch_off + wsub * (PROWS * PROW);
     constexpr int LPR = WTN / EPC;                     // lanes per output row (16 bytes each)
     constexpr int RPI = 64 / LPR;                      // rows per wave-instruction
     const int rr = lane / LPR, cc = (lane % LPR) * EPC;
@@ -230,7 +305,7 @@ __global__ __launch_bounds__(512, MINW) void conv_igemm_kernel(const ConvArgs a)
     }
 }
 
-template <int DT, int BN, int BM, int WN, int WM, int MINW>
+template <int DT, int BN, int BM, int WN, int WM, int KS, int MINW>
 static int launch(const ConvArgs& a, hipStream_t stream) {
     constexpr int NSTAGE = 3;
     const long long tiles_m = (a.M + BM - 1) / BM;
@@ -238,18 +313,19 @@ static int launch(const ConvArgs& a, hipStream_t stream) {
     if (blocks <= 0 || blocks > 0x7fffffffLL) return set_error(AF_ERR_ARG, "conv: grid of %lld workgroups", blocks);
     // LDS actually needed: the ring slots this layer's K loop touches, or the epilogue patches
     constexpr int TMv = BM / WM / 16;
-    constexpr int patch_bytes = 8 * ((TMv >= 2 ? TMv / 2 : TMv) * 16) * (BN / WN + 4) * 4;
+    constexpr int red_bytes = KS == 2 ? WN * WM * (BN / WN / 16) * TMv * 64 * 16 : 0;
+    constexpr int patch_bytes = red_bytes + WN * WM * ((TMv >= 2 ? TMv / 2 : TMv) * 16) * (BN / WN + 4) * 4;
     const int S = a.kt * a.kh * a.kw * a.kpt;
     const int ring_bytes = (S < NSTAGE ? S : NSTAGE) * (BN + BM) * 128;
     const int lds = ring_bytes > patch_bytes ? ring_bytes : patch_bytes;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<DT, BN, BM, WN, WM, NSTAGE, MINW>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<DT, BN, BM, WN, WM, KS, NSTAGE, MINW>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE * (BN + BM) * 128);
         if (e != hipSuccess) return set_error(AF_ERR_LAUNCH, "conv: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_igemm_kernel<DT, BN, BM, WN, WM, NSTAGE, MINW>), dim3((unsigned)blocks), dim3(512), lds, stream, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<DT, BN, BM, WN, WM, KS, NSTAGE, MINW>), dim3((unsigned)blocks), dim3(512), lds, stream, a);
     AF_CHECK_LAUNCH("conv_igemm_kernel");
     return AF_OK;
 }
@@ -275,10 +351,10 @@ static int dispatch(ConvArgs& a, hipStream_t stream) {
     const int v = pick_variant(a.Cout, a.Cin, a.kt * a.kh * a.kw, DT);
     a.tiles_n = a.Cout / ((v == VAR_128x256 || v == VAR_128x128) ? 128 : 64);
     switch (v) {
-        case VAR_128x256: return launch<DT, 128, 256, 2, 4, 2>(a, stream);
-        case VAR_64x256: return launch<DT, 64, 256, 1, 8, 2>(a, stream);
-        case VAR_128x128: return launch<DT, 128, 128, 2, 4, 4>(a, stream);
-        default: return launch<DT, 64, 128, 1, 8, 4>(a, stream);
+        case VAR_128x256: return launch<DT, 128, 256, 2, 4, 1, 2>(a, stream);
+        case VAR_64x256: return launch<DT, 64, 256, 1, 8, 1, 2>(a, stream);
+        case VAR_128x128: return launch<DT, 128, 128, 2, 4, 1, 6>(a, stream);
+        default: return launch<DT, 64, 128, 1, 8, 1, 4>(a, stream);
     }
 }
 
@@ -314,6 +390,7 @@ extern "C" int af_conv3d_bn_act(const af_conv_desc* d, const void* in, const voi
                    aligned16(residual), "conv: buffers must be 16-byte aligned");
     AF_REQUIRE((long long)d->cout * d->kt * d->kh * d->kw * d->cin < (1LL << 31), "conv: weight too large");
     AF_REQUIRE(d->kt * d->kh * d->kw <= 32, "conv: at most 32 kernel taps (got %d)", d->kt * d->kh * d->kw);
+    AF_REQUIRE((long long)d->kt * d->h * d->w * d->cin * dtype_size(d->dtype) < (1LL << 31), "conv: tap offset overflows");
 
     ConvArgs a;
     a.in = (const char*)in; a.w = (const char*)w_packed; a.scale = scale; a.shift = shift;
