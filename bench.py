@@ -151,17 +151,21 @@ def main():
             eng_bytes, kernel_ops = {}, {}
             for i in range(eng.n_ops):
                 op = eng.ops[i]
-                if op.kind in (_lib.AF_OP_CONV, _lib.AF_OP_STEM):
+                if op.kind in (_lib.AF_OP_CONV, _lib.AF_OP_STEM, _lib.AF_OP_CONV_DUAL):
                     cd = op.conv
                     mm = cd.n * cd.to * cd.ho * cd.wo
                     eng_bytes[i] = es * (cd.n * cd.t * cd.h * cd.w * cd.cin + mm * cd.cout * (2 if op.residual else 1)
                                          + cd.cout * cd.cin * cd.kt * cd.kh * cd.kw)
+                    if op.kind == _lib.AF_OP_CONV_DUAL:
+                        c2 = op.conv2
+                        eng_bytes[i] += es * (c2.n * c2.t * c2.h * c2.w * c2.cin // (c2.sh * c2.sw) + c2.cout * c2.cin)
                 cls = TAG_NAMES[op.tag]
                 c = per_class.setdefault(cls, {"ms": 0.0, "macs": 0, "launches": 0})
                 c["ms"] += ms[i]; c["macs"] += eng.op_macs[i]; c["launches"] += 1
-                if op.kind == _lib.AF_OP_CONV:
+                if op.kind in (_lib.AF_OP_CONV, _lib.AF_OP_CONV_DUAL):
                     import ctypes as C
-                    kname = _lib.lib.af_conv_variant_name(_lib.lib.af_conv_variant(C.byref(op.conv))).decode()
+                    d2 = C.byref(op.conv2) if op.kind == _lib.AF_OP_CONV_DUAL else None
+                    kname = _lib.lib.af_conv_variant_name(_lib.lib.af_conv_variant(C.byref(op.conv), d2)).decode()
                 elif op.kind == _lib.AF_OP_STEM:
                     kname = "stem_kernel"
                 else:
@@ -175,12 +179,12 @@ def main():
                 for i in range(eng.n_ops):
                     op = eng.ops[i]
                     row = {"i": i, "name": eng.op_names[i], "class": TAG_NAMES[op.tag], "ms": round(ms[i], 4)}
-                    if op.kind in (_lib.AF_OP_CONV, _lib.AF_OP_STEM):
+                    if i in eng_bytes:
                         cd = op.conv
                         m = cd.n * cd.to * cd.ho * cd.wo
-                        byts = es * (cd.n * cd.t * cd.h * cd.w * cd.cin + m * cd.cout * (2 if op.residual else 1)
-                                     + cd.cout * cd.cin * cd.kt * cd.kh * cd.kw)
-                        row.update({"M": m, "N": cd.cout, "K": cd.cin * cd.kt * cd.kh * cd.kw,
+                        byts = eng_bytes[i]
+                        row.update({"M": m, "N": cd.cout, "K": cd.cin * cd.kt * cd.kh * cd.kw
+                                    + (op.conv2.cin if op.kind == _lib.AF_OP_CONV_DUAL else 0),
                                     "tflops": round(2 * eng.op_macs[i] / ms[i] / 1e9, 1),
                                     "alg_GBs": round(byts / ms[i] / 1e6, 0)})
                     rows.append(row)

@@ -81,6 +81,10 @@ int af_fold_bn(const float* gamma, const float* beta, const float* mean, const f
 int64_t af_packed_conv_weight_bytes(int cout, int cin, int kt, int kh, int kw, int dtype);
 int af_pack_conv_weight(const float* w_oidhw, int cout, int cin, int kt, int kh, int kw,
                         int dtype, void* packed, void* stream);
+/* same, with each output-channel row multiplied by row_scale[cout] in fp32 before the rounding to `dtype`
+ * (BatchNorm scale folded into the weights: needed when two convolutions share one accumulator, below) */
+int af_pack_conv_weight_scaled(const float* w_oidhw, const float* row_scale, int cout, int cin, int kt, int kh, int kw,
+                               int dtype, void* packed, void* stream);
 
 /* stem weight (64,3,kt,7,7) fp32 -> [kt][7][chunk][64][16 B]: kw padded 7->8, cin 3->4 (zeros) */
 int64_t af_packed_stem_weight_bytes(int cout, int kt, int kh, int dtype);
@@ -116,9 +120,19 @@ int af_conv3d_bn_act(const af_conv_desc* d, const void* in, const void* w_packed
                      const float* scale, const float* shift, const void* residual,
                      void* out, int out_ld, void* stream);
 
-/* which tile variant af_conv3d_bn_act launches for `d` (>= 0) and its kernel name: lets a profiler
- * attribute per-layer device time and FLOPs to a kernel instantiation (bench.py roofline). */
-int af_conv_variant(const af_conv_desc* d);
+/* Block 0 of a stage as ONE launch: relu( bn_c(conv_c(b)) + bn_1(conv_1(x)) ), i.e. the last 1x1x1 of the
+ * bottleneck plus the projection shortcut `branch1` (1x1x1, stride [1,s,s]) of ResBlock
+ * (resnet_helper.py:411-444) accumulated into the same output tile: the shortcut tensor is never written
+ * to or read back from HBM.  Both weights must be packed with their BN scale folded in
+ * (af_pack_conv_weight_scaled); `scale` is then all ones and `shift` = shift_c + shift_1.
+ * d2 describes the shortcut conv over in2 and must land on the same output positions as d. */
+int af_conv3d_dual_bn_act(const af_conv_desc* d, const void* in, const void* w_packed,
+                          const af_conv_desc* d2, const void* in2, const void* w2_packed,
+                          const float* scale, const float* shift, void* out, int out_ld, void* stream);
+
+/* which tile variant af_conv3d_[dual_]bn_act launches for `d` (+ optional `d2`) (>= 0) and its kernel name:
+ * lets a profiler attribute per-layer device time and FLOPs to a kernel instantiation (bench.py roofline). */
+int af_conv_variant(const af_conv_desc* d, const af_conv_desc* d2);
 const char* af_conv_variant_name(int variant);
 
 /* nn.MaxPool3d on NDHWC (stem_helper.py:168-170 [1,3,3]/[1,2,2]/[0,1,1];
@@ -134,7 +148,7 @@ int af_avgpool_fc(const af_pool_desc* d, const void* in, const float* fc_w, cons
 /* ---- whole-forward op list ------------------------------------------------------------ */
 
 enum af_op_kind { AF_OP_STEM = 0, AF_OP_CONV = 1, AF_OP_MAXPOOL = 2, AF_OP_HEAD = 3,
-                  AF_OP_PACK_F32 = 4, AF_OP_PACK_U8 = 5 };
+                  AF_OP_PACK_F32 = 4, AF_OP_PACK_U8 = 5, AF_OP_CONV_DUAL = 6 };
 
 typedef struct af_op {
     int32_t kind;                    /* af_op_kind */
@@ -150,6 +164,10 @@ typedef struct af_op {
     void* aux;                       /* HEAD: pooled features (optional) */
     int32_t num_classes;
     int32_t tag;                     /* caller-defined (e.g. layer class) - echoed by *_timed */
+    /* CONV_DUAL only: the projection-shortcut segment */
+    af_conv_desc conv2;
+    const void* in2;
+    const void* weight2;
     /* PACK_* only */
     int64_t in_strides[5];           /* n,c,t,h,w element strides of the fp32 source */
     float mean[3], std_[3];

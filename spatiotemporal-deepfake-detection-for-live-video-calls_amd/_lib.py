@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AF_HIP_LIB") or os.path.join(HERE, "libafhip.so")   # override: kernel experiments
 
 AF_F32, AF_BF16, AF_F16 = 0, 1, 2
-AF_OP_STEM, AF_OP_CONV, AF_OP_MAXPOOL, AF_OP_HEAD, AF_OP_PACK_F32, AF_OP_PACK_U8 = range(6)
+AF_OP_STEM, AF_OP_CONV, AF_OP_MAXPOOL, AF_OP_HEAD, AF_OP_PACK_F32, AF_OP_PACK_U8, AF_OP_CONV_DUAL = range(7)
 AF_ABI_VERSION = 1
 STEM_PAD_T, STEM_PAD_H, STEM_PAD_W_LEFT, STEM_PAD_W_TOTAL, STEM_CPAD = 2, 3, 3, 8, 4
 
@@ -32,6 +32,7 @@ class Op(C.Structure):
         ("in_", C.c_void_p), ("weight", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p),
         ("residual", C.c_void_p), ("out", C.c_void_p), ("aux", C.c_void_p),
         ("num_classes", C.c_int32), ("tag", C.c_int32),
+        ("conv2", ConvDesc), ("in2", C.c_void_p), ("weight2", C.c_void_p),
         ("in_strides", C.c_int64 * 5),
         ("mean", C.c_float * 3), ("std_", C.c_float * 3),
     ]
@@ -45,6 +46,7 @@ ABI = {
     "af_fold_bn": (C.c_int, [C.c_void_p] * 4 + [C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "af_packed_conv_weight_bytes": (C.c_int64, [C.c_int] * 6),
     "af_pack_conv_weight": (C.c_int, [C.c_void_p] + [C.c_int] * 6 + [C.c_void_p, C.c_void_p]),
+    "af_pack_conv_weight_scaled": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p, C.c_void_p]),
     "af_packed_stem_weight_bytes": (C.c_int64, [C.c_int] * 4),
     "af_pack_stem_weight": (C.c_int, [C.c_void_p] + [C.c_int] * 5 + [C.c_void_p, C.c_void_p]),
     "af_stem_input_bytes": (C.c_int64, [C.c_int] * 5),
@@ -53,7 +55,9 @@ ABI = {
                                                                   C.c_int, C.c_void_p, C.c_void_p]),
     "af_stem_conv_bn_relu": (C.c_int, [C.POINTER(ConvDesc)] + [C.c_void_p] * 6),
     "af_conv3d_bn_act": (C.c_int, [C.POINTER(ConvDesc)] + [C.c_void_p] * 6 + [C.c_int, C.c_void_p]),
-    "af_conv_variant": (C.c_int, [C.POINTER(ConvDesc)]),
+    "af_conv3d_dual_bn_act": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_void_p, C.POINTER(ConvDesc)] + [C.c_void_p] * 5
+                              + [C.c_int, C.c_void_p]),
+    "af_conv_variant": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvDesc)]),
     "af_conv_variant_name": (C.c_char_p, [C.c_int]),
     "af_maxpool3d": (C.c_int, [C.POINTER(PoolDesc), C.c_void_p, C.c_void_p, C.c_void_p]),
     "af_avgpool_fc": (C.c_int, [C.POINTER(PoolDesc)] + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 3),

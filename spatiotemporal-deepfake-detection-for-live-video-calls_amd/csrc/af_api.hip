@@ -21,6 +21,9 @@ static int run_one(const af_op& op, hipStream_t s) {
             return af_stem_conv_bn_relu(&op.conv, op.in, op.weight, op.scale, op.shift, op.out, s);
         case AF_OP_CONV:
             return af_conv3d_bn_act(&op.conv, op.in, op.weight, op.scale, op.shift, op.residual, op.out, op.out_ld, s);
+        case AF_OP_CONV_DUAL:
+            return af_conv3d_dual_bn_act(&op.conv, op.in, op.weight, &op.conv2, op.in2, op.weight2, op.scale, op.shift,
+                                         op.out, op.out_ld, s);
         case AF_OP_MAXPOOL:
             return af_maxpool3d(&op.pool, op.in, op.out, s);
         case AF_OP_HEAD:

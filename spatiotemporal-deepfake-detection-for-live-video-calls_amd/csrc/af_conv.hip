@@ -37,6 +37,11 @@ struct ConvArgs {
     long long M;        // N*To*Ho*Wo
     int tiles_n;        // Cout / BN
     int kpt;            // K-steps per tap = Cin / BK
+    // optional second K segment: a 1x1x1 (strided) conv over another input that lands on the same output
+    // positions - the projection shortcut of a res block, accumulated into the same tile (kpt2 == 0: none)
+    const char* in2;
+    const char* w2;
+    int T2, H2, W2, Cin2, st2, sh2, sw2, kpt2;
 };
 
 // 128 bytes of zeros in HBM: the source of every out-of-bounds (padding) tap, so that zero padding
@@ -56,7 +61,8 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // 8 waves (512 threads); wave (wn, wm) owns a (BN/WN) x (BM/WM) sub-tile of 16x16 MFMA tiles.
 // KS = 2 splits each stage's K between wave groups 0-3 / 4-7 (used for Cout = 64: every wave then owns a
 // 64x64 sub-tile, halving LDS fragment traffic per MFMA; the two partial sums meet in LDS after the loop).
-template <int DT, int BN, int BM, int WN, int WM, int KS, int NSTAGE, int MINW>
+// DUAL compiles in the second K segment (projection shortcut accumulated into the same tile).
+template <int DT, int BN, int BM, int WN, int WM, int KS, int NSTAGE, int MINW, bool DUAL>
 __global__ __launch_bounds__(512, MINW) void conv_igemm_kernel(const ConvArgs a) {
     typedef Elem<DT> E;
     constexpr int EPC = E::EPC;            // elements per 16-byte chunk
@@ -91,18 +97,23 @@ __global__ __launch_bounds__(512, MINW) void conv_igemm_kernel(const ConvArgs a)
     const int taps = a.kt * a.kh * a.kw;
     const long long m0 = (long long)tile_m * BM;
     const char* xptr[RX];
-    unsigned xmask[RX];
+    const char* x2ptr[RX];
+    unsigned xmask[RX];                                 // bit t: tap t in bounds; bit 31: row < M
 #pragma unroll
     for (int i = 0; i < RX; ++i) {
         long long m = m0 + lrow + 64 * i;
         xmask[i] = 0;
         xptr[i] = a.in;
+        x2ptr[i] = a.in;
         if (m < a.M) {
             int wo = (int)(m % a.Wo); long long t1 = m / a.Wo;
             int ho = (int)(t1 % a.Ho); long long t2 = t1 / a.Ho;
             int to = (int)(t2 % a.To); long long n = t2 / a.To;
             const int ti0 = to * a.st - a.pt, hi0 = ho * a.sh - a.ph, wi0 = wo * a.sw - a.pw;
             xptr[i] = a.in + ((((n * a.T + ti0) * a.H + hi0) * a.W + wi0) * a.Cin + chunk * EPC) * ES;
+            xmask[i] = 1u << 31;
+            if (DUAL)
+                x2ptr[i] = a.in2 + ((((n * a.T2 + to * a.st2) * a.H2 + ho * a.sh2) * a.W2 + wo * a.sw2) * a.Cin2 + chunk * EPC) * ES;
             int tap = 0;
             for (int dt = 0; dt < a.kt; ++dt)
                 for (int dh = 0; dh < a.kh; ++dh)
@@ -115,8 +126,12 @@ __global__ __launch_bounds__(512, MINW) void conv_igemm_kernel(const ConvArgs a)
     }
     const long long Kw = (long long)taps * a.Cin;      // weight row length (elements)
     const char* wptr[RW];
+    const char* w2ptr[RW];
 #pragma unroll
-    for (int i = 0; i < RW; ++i) wptr[i] = a.w + ((tile_n * BN + lrow + 64 * i) * Kw + chunk * EPC) * ES;
+    for (int i = 0; i < RW; ++i) {
+        wptr[i] = a.w + ((tile_n * BN + lrow + 64 * i) * Kw + chunk * EPC) * ES;
+        w2ptr[i] = a.w2 + ((long long)(tile_n * BN + lrow + 64 * i) * a.Cin2 + chunk * EPC) * ES;
+    }
     const char* zero = reinterpret_cast<const char*>(g_zero_page);
 
     // ---- LDS-DMA producer: stage `st` <- K-step (kc, tap).  The TAPS are the inner loop: for one 64-channel
@@ -128,7 +143,11 @@ __global__ __launch_bounds__(512, MINW) void conv_igemm_kernel(const ConvArgs a)
     int dt = 0, dh = 0, dw = 0, kc = 0, tap = 0;
     auto issue_piece = [&](int st, int g) {
         const unsigned base = lds0 + st * STAGE_BYTES + wave * (8 * 128) + g * (64 * 128);
-        if (g < RW) {
+        if (DUAL && kc >= a.kpt) {                               // second segment (projection shortcut)
+            const int off2 = (kc - a.kpt) * 128;
+            if (g < RW) glds16(w2ptr[g] + off2, base);
+            else glds16((xmask[g - RW] >> 31) ? x2ptr[g - RW] + off2 : zero, base);
+        } else if (g < RW) {
             glds16(wptr[g] + (long long)(tap * a.Cin * ES + kc * 128), base);
         } else {
             const int xoff = ((dt * a.H + dh) * a.W + dw) * a.Cin * ES + kc * 128;   // < 2^31 (host-checked)
@@ -137,6 +156,7 @@ __global__ __launch_bounds__(512, MINW) void conv_igemm_kernel(const ConvArgs a)
         }
     };
     auto advance = [&]() {
+        if (DUAL && kc >= a.kpt) { ++kc; return; }
         ++tap;
         if (++dw == a.kw) {
             dw = 0;
@@ -158,27 +178,26 @@ __global__ __launch_bounds__(512, MINW) void conv_igemm_kernel(const ConvArgs a)
 #pragma unroll
         for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int S = taps * a.kpt;
+    const int S = taps * a.kpt + (DUAL ? a.kpt2 : 0);
     issue_stage(0);
     if (S > 1) issue_stage(1);
 
     const int frow = lane & 15, fg = lane >> 4;
     constexpr int NKK = 2 / KS;                                   // k-halves of a stage this wave multiplies
-    constexpr int NT = NKK * TN * TM;                             // 16x16 tile products per stage per wave
     const int kk0 = KS == 2 ? kgroup : 0;
-    int st = 0;
-    for (int s = 0; s < S; ++s) {
-        // stage s has landed for this wave once only the younger stage (s+1) is still in flight ...
-        if (s + 1 < S) wait_vmcnt<PER_WAVE>(); else wait_vmcnt<0>();
-        // ... and for every wave after the barrier, which also retires all reads of slot (s-1)%3
-        __builtin_amdgcn_s_barrier();
-        const bool refill = s + 2 < S;                            // slot (s+2)%3 == (s-1)%3 is free now
-        const int nst = st == 0 ? 2 : st - 1;
-        const uint4* ws = smem + st * (STAGE_BYTES / 16) + (wn * WTN + frow) * 8;
-        const uint4* xs = smem + st * (STAGE_BYTES / 16) + BN * 8 + (wm * WTM + frow) * 8;
-        if (LEAN) {
-            // HBM-bound short-K variants: smallest register footprint (more workgroups per CU)
-            if (refill) issue_stage(nst);
+    const int wrow = (wn * WTN + frow) * 8, xrow = BN * 8 + (wm * WTM + frow) * 8;
+    if (LEAN || NKK == 1 || TM < 4) {
+        // HBM-bound short-K variants (and the K-split layout): smallest register footprint, one barrier per
+        // K-step, all DMA pieces of stage s+2 issued right after it.
+        int st = 0;
+        for (int s = 0; s < S; ++s) {
+            // stage s has landed for this wave once only the younger stage (s+1) is still in flight ...
+            if (s + 1 < S) wait_vmcnt<PER_WAVE>(); else wait_vmcnt<0>();
+            // ... and for every wave after the barrier, which also retires all reads of slot (s-1)%3
+            __builtin_amdgcn_s_barrier();
+            if (s + 2 < S) issue_stage(st == 0 ? 2 : st - 1);    // slot (s+2)%3 == (s-1)%3 is free now
+            const uint4* ws = smem + st * (STAGE_BYTES / 16) + wrow;
+            const uint4* xs = smem + st * (STAGE_BYTES / 16) + xrow;
 #pragma unroll
             for (int q = 0; q < NKK; ++q) {
                 const int c = ((kk0 + q) * 4 + fg) ^ (frow & 7);
@@ -192,40 +211,69 @@ __global__ __launch_bounds__(512, MINW) void conv_igemm_kernel(const ConvArgs a)
 #pragma unroll
                     for (int j = 0; j < TM; ++j) Mma<DT>::run(af[i], bf[j], acc[i][j]);
             }
-        } else {
-            // MFMA-bound variants: all fragment reads of the stage go out first; then the LDS-DMA pieces of stage
-            // s+2 (SALU m0 juggling + address VALU + a ~60-cycle VMEM issue each) are tucked BETWEEN groups of
-            // MFMAs, so the matrix pipe keeps running under them (and under the partner wave's) instead of idling
-            // through a load-issue phase after every barrier.  sched_barrier pins the interleave.
-            uint4 af[NKK][TN], bf[NKK][TM];
-#pragma unroll
-            for (int q = 0; q < NKK; ++q) {
-                const int c = ((kk0 + q) * 4 + fg) ^ (frow & 7);
-#pragma unroll
-                for (int i = 0; i < TN; ++i) af[q][i] = ws[i * 16 * 8 + c];
-#pragma unroll
-                for (int j = 0; j < TM; ++j) bf[q][j] = xs[j * 16 * 8 + c];
-            }
-            constexpr int MPG = NT / (PER_WAVE + 1);              // tile products between two pieces
-#pragma unroll
-            for (int g = 0; g <= PER_WAVE; ++g) {
-                if (g < PER_WAVE) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (refill) issue_piece(nst, g);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                const int lo = g * MPG, hi = (g == PER_WAVE) ? NT : (g + 1) * MPG;
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    if (t >= lo && t < hi) {
-                        const int q = t / (TN * TM), i = (t % (TN * TM)) / TM, j = t % TM;
-                        Mma<DT>::run(af[q][i], bf[q][j], acc[i][j]);
-                    }
-                }
-            }
-            if (refill) advance();
+            st = (st == 2) ? 0 : st + 1;
         }
-        st = (st == 2) ? 0 : st + 1;
+    } else {
+        // MFMA-bound variants: software-pipelined by k-HALVES.  The fragments of a half are read from LDS while
+        // the MFMAs of the previous half run, so the matrix pipe never waits for the LDS fill that follows a
+        // barrier; the barrier (+ the counted vmcnt that makes stage s+1 visible) sits between the two MFMA
+        // groups of a stage, and the LDS-DMA pieces of stage s+2 (SALU m0 juggling, address VALU, ~60-cycle VMEM
+        // issue each) are tucked between the MFMAs of the first group.  sched_barrier pins the interleave.
+        constexpr int NTH = TN * TM;                              // tile products per k-half
+        constexpr int MPG = (NTH + PER_WAVE - 1) / PER_WAVE;      // products between two DMA pieces
+        uint4 a0[TN], b0[TM], a1[TN], b1[TM];
+        auto read_half = [&](uint4 (&af)[TN], uint4 (&bf)[TM], int st_, int kk) {
+            const int c = (kk * 4 + fg) ^ (frow & 7);
+            const uint4* ws = smem + st_ * (STAGE_BYTES / 16) + wrow;
+            const uint4* xs = smem + st_ * (STAGE_BYTES / 16) + xrow;
+#pragma unroll
+            for (int i = 0; i < TN; ++i) af[i] = ws[i * 16 * 8 + c];
+#pragma unroll
+            for (int j = 0; j < TM; ++j) bf[j] = xs[j * 16 * 8 + c];
+        };
+        wait_vmcnt<0>();                                          // prologue: stage 0 (and 1) landed
+        __builtin_amdgcn_s_barrier();
+        read_half(a0, b0, 0, 0);
+        int st = 0;
+        // all stages but the last (the last one is peeled: no barrier / look-ahead read in it, and - just as
+        // important - no control-flow merge in the steady-state body, which would make hipcc's LDS wait counts
+        // conservative and stall the second MFMA group on the look-ahead reads)
+        for (int s = 0; s + 1 < S; ++s) {
+            const bool refill = s + 2 < S;                        // slot (s+2)%3 == (s-1)%3: its last reads were
+            const int nst = st == 0 ? 2 : st - 1;                 // retired before the previous mid-step barrier
+            const int st1 = st == 2 ? 0 : st + 1;
+            read_half(a1, b1, st, 1);
+            // ---- first half: MFMA(a0,b0) with the DMA pieces of stage s+2 in the gaps
+#pragma unroll
+            for (int g = 0; g < PER_WAVE; ++g) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (refill) issue_piece(nst, g);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = g * MPG; t < (g + 1) * MPG && t < NTH; ++t) Mma<DT>::run(a0[t / TM], b0[t % TM], acc[t / TM][t % TM]);
+            }
+#pragma unroll
+            for (int t = PER_WAVE * MPG; t < NTH; ++t) Mma<DT>::run(a0[t / TM], b0[t % TM], acc[t / TM][t % TM]);
+            if (refill) advance();
+            __builtin_amdgcn_sched_barrier(0);
+            // this wave's reads of stage s are back (they were issued a whole MFMA group ago) and its pieces of
+            // stage s+1 have landed; after the barrier that holds for every wave
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (refill) wait_vmcnt<PER_WAVE>(); else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            read_half(a0, b0, st1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- second half: MFMA(a1,b1) runs under the LDS reads just issued
+#pragma unroll
+            for (int t = 0; t < NTH; ++t) Mma<DT>::run(a1[t / TM], b1[t % TM], acc[t / TM][t % TM]);
+            __builtin_amdgcn_sched_barrier(0);
+            st = st1;
+        }
+        read_half(a1, b1, st, 1);                                 // last stage
+#pragma unroll
+        for (int t = 0; t < NTH; ++t) Mma<DT>::run(a0[t / TM], b0[t % TM], acc[t / TM][t % TM]);
+#pragma unroll
+        for (int t = 0; t < NTH; ++t) Mma<DT>::run(a1[t / TM], b1[t % TM], acc[t / TM][t % TM]);
     }
 
     // ---- epilogue.  The MFMA accumulator holds 4 consecutive channels of one position per lane: fine for
@@ -305,7 +353,7 @@ __global__ __launch_bounds__(512, MINW) void conv_igemm_kernel(const ConvArgs a)
     }
 }
 
-template <int DT, int BN, int BM, int WN, int WM, int KS, int MINW>
+template <int DT, int BN, int BM, int WN, int WM, int KS, int MINW, bool DUAL>
 static int launch(const ConvArgs& a, hipStream_t stream) {
     constexpr int NSTAGE = 3;
     const long long tiles_m = (a.M + BM - 1) / BM;
@@ -315,17 +363,17 @@ static int launch(const ConvArgs& a, hipStream_t stream) {
     constexpr int TMv = BM / WM / 16;
     constexpr int red_bytes = KS == 2 ? WN * WM * (BN / WN / 16) * TMv * 64 * 16 : 0;
     constexpr int patch_bytes = red_bytes + WN * WM * ((TMv >= 2 ? TMv / 2 : TMv) * 16) * (BN / WN + 4) * 4;
-    const int S = a.kt * a.kh * a.kw * a.kpt;
+    const int S = a.kt * a.kh * a.kw * a.kpt + a.kpt2;
     const int ring_bytes = (S < NSTAGE ? S : NSTAGE) * (BN + BM) * 128;
     const int lds = ring_bytes > patch_bytes ? ring_bytes : patch_bytes;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<DT, BN, BM, WN, WM, KS, NSTAGE, MINW>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<DT, BN, BM, WN, WM, KS, NSTAGE, MINW, DUAL>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE * (BN + BM) * 128);
         if (e != hipSuccess) return set_error(AF_ERR_LAUNCH, "conv: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_igemm_kernel<DT, BN, BM, WN, WM, KS, NSTAGE, MINW>), dim3((unsigned)blocks), dim3(512), lds, stream, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<DT, BN, BM, WN, WM, KS, NSTAGE, MINW, DUAL>), dim3((unsigned)blocks), dim3(512), lds, stream, a);
     AF_CHECK_LAUNCH("conv_igemm_kernel");
     return AF_OK;
 }
@@ -338,8 +386,8 @@ enum { VAR_128x256 = 0, VAR_64x256 = 1, VAR_128x128 = 2, VAR_64x128 = 3, VAR_COU
 static const char* const kVariantNames[] = {"conv_igemm<BN=128,BM=256>", "conv_igemm<BN=64,BM=256>",
                                             "conv_igemm<BN=128,BM=128>", "conv_igemm<BN=64,BM=128>"};
 
-static int pick_variant(int cout, int cin, int taps, int dtype) {
-    const int ksteps = taps * (cin / (dtype == AF_F32 ? 32 : 64));
+static int pick_variant(int cout, int cin, int taps, int dtype, int cin2 = 0) {
+    const int ksteps = (taps * cin + cin2) / (dtype == AF_F32 ? 32 : 64);
     const bool wide = cout % 128 == 0, short_k = ksteps <= 3;
     return wide ? (short_k ? VAR_128x128 : VAR_128x256) : (short_k ? VAR_64x128 : VAR_64x256);
 }
@@ -348,29 +396,36 @@ template <int DT>
 static int dispatch(ConvArgs& a, hipStream_t stream) {
     constexpr int BK = 8 * Elem<DT>::EPC;
     a.kpt = a.Cin / BK;
-    const int v = pick_variant(a.Cout, a.Cin, a.kt * a.kh * a.kw, DT);
+    a.kpt2 = a.in2 ? a.Cin2 / BK : 0;
+    const int v = pick_variant(a.Cout, a.Cin, a.kt * a.kh * a.kw, DT, a.in2 ? a.Cin2 : 0);
     a.tiles_n = a.Cout / ((v == VAR_128x256 || v == VAR_128x128) ? 128 : 64);
+    if (a.in2) {                                 // projection blocks: cout is a multiple of 256
+        if (v == VAR_128x256) return launch<DT, 128, 256, 2, 4, 1, 2, true>(a, stream);
+        if (v == VAR_128x128) return launch<DT, 128, 128, 2, 4, 1, 6, true>(a, stream);
+        return set_error(AF_ERR_ARG, "conv_dual: cout must be a multiple of 128");
+    }
     switch (v) {
-        case VAR_128x256: return launch<DT, 128, 256, 2, 4, 1, 2>(a, stream);
-        case VAR_64x256: return launch<DT, 64, 256, 1, 8, 1, 2>(a, stream);
-        case VAR_128x128: return launch<DT, 128, 128, 2, 4, 1, 6>(a, stream);
-        default: return launch<DT, 64, 128, 1, 8, 1, 4>(a, stream);
+        case VAR_128x256: return launch<DT, 128, 256, 2, 4, 1, 2, false>(a, stream);
+        case VAR_64x256: return launch<DT, 64, 256, 1, 8, 1, 2, false>(a, stream);
+        case VAR_128x128: return launch<DT, 128, 128, 2, 4, 1, 6, false>(a, stream);
+        default: return launch<DT, 64, 128, 1, 8, 1, 4, false>(a, stream);
     }
 }
 
 }  // namespace af
 
-extern "C" int af_conv_variant(const af_conv_desc* d) {
+extern "C" int af_conv_variant(const af_conv_desc* d, const af_conv_desc* d2) {
     AF_REQUIRE(d && d->cout > 0 && d->cin > 0 && af::dtype_ok(d->dtype), "conv_variant: bad descriptor");
-    return af::pick_variant(d->cout, d->cin, d->kt * d->kh * d->kw, d->dtype);
+    return af::pick_variant(d->cout, d->cin, d->kt * d->kh * d->kw, d->dtype, d2 ? d2->cin : 0);
 }
 
 extern "C" const char* af_conv_variant_name(int variant) {
     return (variant >= 0 && variant < af::VAR_COUNT) ? af::kVariantNames[variant] : "?";
 }
 
-extern "C" int af_conv3d_bn_act(const af_conv_desc* d, const void* in, const void* w_packed, const float* scale,
-                                const float* shift, const void* residual, void* out, int out_ld, void* stream) {
+static int conv_common(const af_conv_desc* d, const void* in, const void* w_packed, const af_conv_desc* d2,
+                       const void* in2, const void* w2_packed, const float* scale, const float* shift,
+                       const void* residual, void* out, int out_ld, void* stream) {
     using namespace af;
     AF_REQUIRE(d && in && w_packed && scale && shift && out, "conv: null argument");
     AF_REQUIRE(dtype_ok(d->dtype), "conv: bad dtype %d", d->dtype);
@@ -389,7 +444,7 @@ extern "C" int af_conv3d_bn_act(const af_conv_desc* d, const void* in, const voi
     AF_REQUIRE(aligned16(in) && aligned16(w_packed) && aligned16(scale) && aligned16(shift) && aligned16(out) &&
                    aligned16(residual), "conv: buffers must be 16-byte aligned");
     AF_REQUIRE((long long)d->cout * d->kt * d->kh * d->kw * d->cin < (1LL << 31), "conv: weight too large");
-    AF_REQUIRE(d->kt * d->kh * d->kw <= 32, "conv: at most 32 kernel taps (got %d)", d->kt * d->kh * d->kw);
+    AF_REQUIRE(d->kt * d->kh * d->kw <= 31, "conv: at most 31 kernel taps (got %d)", d->kt * d->kh * d->kw);
     AF_REQUIRE((long long)d->kt * d->h * d->w * d->cin * dtype_size(d->dtype) < (1LL << 31), "conv: tap offset overflows");
 
     ConvArgs a;
@@ -400,10 +455,34 @@ extern "C" int af_conv3d_bn_act(const af_conv_desc* d, const void* in, const voi
     a.pt = d->pt; a.ph = d->ph; a.pw = d->pw; a.To = to; a.Ho = ho; a.Wo = wo;
     a.relu = d->relu; a.out_ld = out_ld;
     a.M = (long long)d->n * to * ho * wo;
+    a.in2 = nullptr; a.w2 = (const char*)w_packed; a.T2 = a.H2 = a.W2 = 1; a.Cin2 = bk; a.st2 = a.sh2 = a.sw2 = 1; a.kpt2 = 0;
+    if (d2) {
+        AF_REQUIRE(in2 && w2_packed && aligned16(in2) && aligned16(w2_packed), "conv: second segment needs in2 / w2");
+        AF_REQUIRE(d2->dtype == d->dtype && d2->n == d->n && d2->cout == d->cout, "conv: second segment dtype/n/cout mismatch");
+        AF_REQUIRE(d2->kt == 1 && d2->kh == 1 && d2->kw == 1 && d2->pt == 0 && d2->ph == 0 && d2->pw == 0,
+                   "conv: second segment must be a 1x1x1 convolution without padding");
+        AF_REQUIRE(d2->st > 0 && d2->sh > 0 && d2->sw > 0 && (d2->t - 1) / d2->st + 1 == to && (d2->h - 1) / d2->sh + 1 == ho &&
+                       (d2->w - 1) / d2->sw + 1 == wo, "conv: second segment does not land on the same output positions");
+        AF_REQUIRE(d2->cin > 0 && d2->cin % bk == 0, "conv: second segment cin=%d must be a multiple of %d", d2->cin, bk);
+        a.in2 = (const char*)in2; a.w2 = (const char*)w2_packed;
+        a.T2 = d2->t; a.H2 = d2->h; a.W2 = d2->w; a.Cin2 = d2->cin; a.st2 = d2->st; a.sh2 = d2->sh; a.sw2 = d2->sw;
+    }
     hipStream_t s = (hipStream_t)stream;
     switch (d->dtype) {
         case AF_F32: return dispatch<AF_F32>(a, s);
         case AF_BF16: return dispatch<AF_BF16>(a, s);
         default: return dispatch<AF_F16>(a, s);
     }
+}
+
+extern "C" int af_conv3d_bn_act(const af_conv_desc* d, const void* in, const void* w_packed, const float* scale,
+                                const float* shift, const void* residual, void* out, int out_ld, void* stream) {
+    return conv_common(d, in, w_packed, nullptr, nullptr, nullptr, scale, shift, residual, out, out_ld, stream);
+}
+
+extern "C" int af_conv3d_dual_bn_act(const af_conv_desc* d, const void* in, const void* w_packed,
+                                     const af_conv_desc* d2, const void* in2, const void* w2_packed, const float* scale,
+                                     const float* shift, void* out, int out_ld, void* stream) {
+    AF_REQUIRE(d2, "conv_dual: null second descriptor");
+    return conv_common(d, in, w_packed, d2, in2, w2_packed, scale, shift, nullptr, out, out_ld, stream);
 }

@@ -17,14 +17,16 @@ __global__ void fold_bn_kernel(const float* gamma, const float* beta, const floa
 
 // OIDHW fp32 -> [o][tap][i] in DT
 template <int DT>
-__global__ void pack_conv_weight_kernel(const float* __restrict__ w, int cout, int cin, int taps,
-                                        typename Elem<DT>::type* __restrict__ out) {
+__global__ void pack_conv_weight_kernel(const float* __restrict__ w, const float* __restrict__ row_scale, int cout,
+                                        int cin, int taps, typename Elem<DT>::type* __restrict__ out) {
     long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;      // over output elements
     long long total = (long long)cout * taps * cin;
     if (idx >= total) return;
     int i = (int)(idx % cin); long long r = idx / cin;
     int tap = (int)(r % taps); int o = (int)(r / taps);
-    out[idx] = Elem<DT>::from_f32(w[((long long)o * cin + i) * taps + tap]);
+    float v = w[((long long)o * cin + i) * taps + tap];
+    if (row_scale) v *= row_scale[o];               // BN scale folded in fp32, before the one rounding
+    out[idx] = Elem<DT>::from_f32(v);
 }
 
 // (cout,3,kt,kh,7) fp32 -> [kt][kh][NCH][cout][EPC]: K-row (dt,dh) = 8 pixels x 4 channels, zero padded
@@ -99,19 +101,24 @@ extern "C" int64_t af_packed_conv_weight_bytes(int cout, int cin, int kt, int kh
     return (int64_t)cout * cin * kt * kh * kw * dtype_size(dtype);
 }
 
-extern "C" int af_pack_conv_weight(const float* w, int cout, int cin, int kt, int kh, int kw, int dtype, void* packed,
-                                   void* stream) {
+extern "C" int af_pack_conv_weight_scaled(const float* w, const float* row_scale, int cout, int cin, int kt, int kh,
+                                          int kw, int dtype, void* packed, void* stream) {
     AF_REQUIRE(w && packed && dtype_ok(dtype) && cout > 0 && cin > 0 && kt > 0 && kh > 0 && kw > 0,
                "pack_conv_weight: bad argument");
     const int taps = kt * kh * kw;
     const long long total = (long long)cout * cin * taps;
     hipStream_t s = (hipStream_t)stream;
     dim3 g(grid_for(total, 256)), b(256);
-    if (dtype == AF_F32) hipLaunchKernelGGL((pack_conv_weight_kernel<AF_F32>), g, b, 0, s, w, cout, cin, taps, (float*)packed);
-    else if (dtype == AF_BF16) hipLaunchKernelGGL((pack_conv_weight_kernel<AF_BF16>), g, b, 0, s, w, cout, cin, taps, (__bf16*)packed);
-    else hipLaunchKernelGGL((pack_conv_weight_kernel<AF_F16>), g, b, 0, s, w, cout, cin, taps, (_Float16*)packed);
+    if (dtype == AF_F32) hipLaunchKernelGGL((pack_conv_weight_kernel<AF_F32>), g, b, 0, s, w, row_scale, cout, cin, taps, (float*)packed);
+    else if (dtype == AF_BF16) hipLaunchKernelGGL((pack_conv_weight_kernel<AF_BF16>), g, b, 0, s, w, row_scale, cout, cin, taps, (__bf16*)packed);
+    else hipLaunchKernelGGL((pack_conv_weight_kernel<AF_F16>), g, b, 0, s, w, row_scale, cout, cin, taps, (_Float16*)packed);
     AF_CHECK_LAUNCH("pack_conv_weight_kernel");
     return AF_OK;
+}
+
+extern "C" int af_pack_conv_weight(const float* w, int cout, int cin, int kt, int kh, int kw, int dtype, void* packed,
+                                   void* stream) {
+    return af_pack_conv_weight_scaled(w, nullptr, cout, cin, kt, kh, kw, dtype, packed, stream);
 }
 
 extern "C" int64_t af_packed_stem_weight_bytes(int cout, int kt, int kh, int dtype) {

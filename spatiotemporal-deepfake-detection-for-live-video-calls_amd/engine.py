@@ -75,6 +75,23 @@ class PackedWeights:
                 check(lib.af_pack_conv_weight(_ptr(w), cv.cout, cv.cin, kt, kh, kw, code, _ptr(packed), st),
                       "af_pack_conv_weight")
             self.w[cv.conv], self.scale[cv.conv], self.shift[cv.conv] = packed, scale, shift
+        # block 0 of every stage: last 1x1x1 + projection shortcut share one accumulator (af_conv3d_dual_bn_act):
+        # both weights get their BN scale folded in (fp32, before the rounding), shifts are summed
+        self.w_folded, self.shift_sum, self.ones = {}, {}, {}
+        for stage in spec.stages:
+            for blk in stage.blocks:
+                if blk.branch1 is None:
+                    continue
+                for cv in (blk.c, blk.branch1):
+                    w = state[cv.conv + ".weight"].detach().to(device=device, dtype=torch.float32).contiguous()
+                    kt, kh, kw = cv.kernel
+                    nbytes = lib.af_packed_conv_weight_bytes(cv.cout, cv.cin, kt, kh, kw, code)
+                    packed = torch.empty(nbytes // es, dtype=_TORCH_DTYPE[dtype], device=device)
+                    check(lib.af_pack_conv_weight_scaled(_ptr(w), _ptr(self.scale[cv.conv]), cv.cout, cv.cin, kt, kh, kw,
+                                                         code, _ptr(packed), st), "af_pack_conv_weight_scaled")
+                    self.w_folded[cv.conv] = packed
+                self.shift_sum[blk.c.conv] = (self.shift[blk.c.conv] + self.shift[blk.branch1.conv]).contiguous()
+                self.ones[blk.c.conv] = torch.ones(blk.c.cout, dtype=torch.float32, device=device)
         self.fc_w = state[spec.head + ".weight"].detach().to(device=device, dtype=torch.float32).contiguous()
         self.fc_b = state[spec.head + ".bias"].detach().to(device=device, dtype=torch.float32).contiguous()
         torch.cuda.current_stream(device).synchronize()      # sources may be freed by the caller
@@ -95,7 +112,7 @@ class Engine:
 
         # ---- walk the network once to size the buffers --------------------------------------
         plan = []           # (kind, spec, in_dims, out_dims, in_buf, out_buf, res_buf)
-        sizes = {"P0": 0, "P1": 0, "A": 0, "B": 0, "SC": 0}
+        sizes = {"P0": 0, "P1": 0, "A": 0, "B": 0}
 
         def need(buf, dims, c):
             sizes[buf] = max(sizes[buf], batch * dims[0] * dims[1] * dims[2] * c)
@@ -113,16 +130,16 @@ class Engine:
         for si, stage in enumerate(spec.stages):
             for blk in stage.blocks:
                 res = cur
-                if blk.branch1 is not None:
-                    ds = blk.branch1.out_dims(*d)
-                    plan.append(("conv", blk.branch1, d, ds, cur, "SC", None)); need("SC", ds, blk.branch1.cout)
-                    res = "SC"
                 da = blk.a.out_dims(*d)
                 plan.append(("conv", blk.a, d, da, cur, "A", None)); need("A", da, blk.a.cout)
                 db = blk.b.out_dims(*da)
                 plan.append(("conv", blk.b, da, db, "A", "B", None)); need("B", db, blk.b.cout)
                 dc = blk.c.out_dims(*db)
-                plan.append(("conv", blk.c, db, dc, "B", nxt, res)); need(nxt, dc, blk.c.cout)
+                if blk.branch1 is not None:      # c conv + projection shortcut in one launch; no shortcut tensor
+                    assert blk.branch1.out_dims(*d) == dc
+                    plan.append(("dual", (blk.c, blk.branch1, d), db, dc, "B", nxt, cur)); need(nxt, dc, blk.c.cout)
+                else:
+                    plan.append(("conv", blk.c, db, dc, "B", nxt, res)); need(nxt, dc, blk.c.cout)
                 cur, nxt = nxt, cur
                 d, c = dc, blk.c.cout
             if si == 0:
@@ -181,6 +198,25 @@ class Engine:
                 op.out_ld = cv.cout
                 self.op_names.append(cv.conv)
                 self.op_macs.append(batch * cv.macs(*din))
+            elif kind == "dual":
+                cvc, cv1, din1 = sp
+                op.kind, op.tag = _lib.AF_OP_CONV_DUAL, _conv_tag(cvc)
+                for cd, cv, dd in ((op.conv, cvc, din), (op.conv2, cv1, din1)):
+                    cd.n, (cd.t, cd.h, cd.w), cd.cin, cd.cout = batch, dd, cv.cin, cv.cout
+                    cd.kt, cd.kh, cd.kw = cv.kernel
+                    cd.st, cd.sh, cd.sw = cv.stride
+                    cd.pt, cd.ph, cd.pw = cv.pad
+                    cd.to, cd.ho, cd.wo = dout
+                    cd.relu, cd.dtype = 1, self.code
+                op.weight = weights.w_folded[cvc.conv].data_ptr()
+                op.weight2 = weights.w_folded[cv1.conv].data_ptr()
+                op.in2 = self.buf[br].data_ptr()
+                op.scale = weights.ones[cvc.conv].data_ptr()
+                op.shift = weights.shift_sum[cvc.conv].data_ptr()
+                op.residual = None
+                op.out_ld = cvc.cout
+                self.op_names.append(cvc.conv + "+branch1")
+                self.op_macs.append(batch * (cvc.macs(*din) + cv1.macs(*din1)))
             elif kind == "pool":
                 p, ch = sp
                 op.kind, op.tag = _lib.AF_OP_MAXPOOL, TAG_POOL
@@ -262,7 +298,7 @@ class Engine:
     def activation(self, op_index: int) -> torch.Tensor:
         """Output of op ``op_index`` as an (N,T,H,W,C) view of its buffer (valid until overwritten)."""
         op = self.ops[op_index]
-        if op.kind in (_lib.AF_OP_STEM, _lib.AF_OP_CONV):
+        if op.kind in (_lib.AF_OP_STEM, _lib.AF_OP_CONV, _lib.AF_OP_CONV_DUAL):
             shape = (op.conv.n, op.conv.to, op.conv.ho, op.conv.wo, op.conv.cout)
         elif op.kind == _lib.AF_OP_MAXPOOL:
             shape = (op.pool.n, op.pool.to, op.pool.ho, op.pool.wo, op.pool.c)

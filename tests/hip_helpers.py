@@ -64,6 +64,45 @@ def conv_bn_act(x_ndhwc, w_oidhw, scale, shift, stride, pad, relu, dtype, residu
     return out
 
 
+def _pack_scaled(w_oidhw, row_scale, dtype):
+    L = lib()
+    code = L.DTYPE_CODES[dtype]
+    cout, cin, kt, kh, kw = w_oidhw.shape
+    wsrc = w_oidhw.float().cuda().contiguous()
+    nbytes = L.lib.af_packed_conv_weight_bytes(cout, cin, kt, kh, kw, code)
+    packed = torch.empty(nbytes // (4 if dtype == "f32" else 2), dtype=TORCH_DT[dtype], device="cuda")
+    L.check(L.lib.af_pack_conv_weight_scaled(_p(wsrc), _p(row_scale), cout, cin, kt, kh, kw, code, _p(packed), _stream()),
+            "pack_conv_weight_scaled")
+    return packed
+
+
+def conv_dual(x_ndhwc, w_oidhw, bn, x2_ndhwc, w2_oidhw, bn2, stride2, dtype):
+    """relu(bn(conv1x1x1(x)) + bn2(conv1x1x1_strided(x2))) as one af_conv3d_dual_bn_act launch."""
+    L = lib()
+    code = L.DTYPE_CODES[dtype]
+    (scale, shift), (scale2, shift2) = bn, bn2
+    n, t, h, w, cin = x_ndhwc.shape
+    cout = w_oidhw.shape[0]
+    d, d2 = L.ConvDesc(), L.ConvDesc()
+    d.n, d.t, d.h, d.w, d.cin, d.cout = n, t, h, w, cin, cout
+    d.kt = d.kh = d.kw = d.st = d.sh = d.sw = 1
+    d.to, d.ho, d.wo, d.relu, d.dtype = t, h, w, 1, code
+    n2, t2, h2, w2, cin2 = x2_ndhwc.shape
+    d2.n, d2.t, d2.h, d2.w, d2.cin, d2.cout = n2, t2, h2, w2, cin2, cout
+    d2.kt = d2.kh = d2.kw = 1
+    d2.st, d2.sh, d2.sw = stride2
+    d2.to, d2.ho, d2.wo, d2.relu, d2.dtype = t, h, w, 1, code
+    out = torch.empty((n, t, h, w, cout), dtype=TORCH_DT[dtype], device="cuda")
+    ones = torch.ones(cout, device="cuda")
+    # keep every device buffer referenced until the launch has been enqueued (the caching allocator would
+    # otherwise hand the first packed weight's memory to the second)
+    pw, pw2, shift_sum = _pack_scaled(w_oidhw, scale, dtype), _pack_scaled(w2_oidhw, scale2, dtype), (shift + shift2).contiguous()
+    L.check(L.lib.af_conv3d_dual_bn_act(C.byref(d), _p(x_ndhwc), _p(pw), C.byref(d2), _p(x2_ndhwc), _p(pw2), _p(ones),
+                                        _p(shift_sum), _p(out), 0, _stream()), "conv3d_dual_bn_act")
+    torch.cuda.current_stream().synchronize()
+    return out
+
+
 def pack_input_f32(x_ncdhw_dev, dtype):
     L = lib()
     code = L.DTYPE_CODES[dtype]

@@ -32,13 +32,17 @@ def _close(got, want, dtype, what, scale=1.0):
     assert err <= hh.LAYER_TOL[dtype] * scale * ref, "%s [%s]: max|d|=%.3e vs max|ref|=%.3e" % (what, dtype, err, ref)
 
 
-def hip_block(x_ncdhw, sd, p, stride, dtype):
+def hip_block(x_ncdhw, sd, p, stride, dtype, fuse_shortcut=True):
     x = hh.to_ndhwc(x_ncdhw, dtype)
     wa = sd[p + ".branch2.a.weight"]
     tk = wa.shape[2]
     a = hh.conv_bn_act(x, wa, *hh.fold_bn(sd, p + ".branch2.a_bn"), (1, 1, 1), (tk // 2, 0, 0), True, dtype)
     b = hh.conv_bn_act(a, sd[p + ".branch2.b.weight"], *hh.fold_bn(sd, p + ".branch2.b_bn"), (1, stride, stride),
                        (0, 1, 1), True, dtype)
+    if (p + ".branch1.weight") in sd and fuse_shortcut:       # what the engine does: one launch for c + branch1
+        out = hh.conv_dual(b, sd[p + ".branch2.c.weight"], hh.fold_bn(sd, p + ".branch2.c_bn"), x,
+                           sd[p + ".branch1.weight"], hh.fold_bn(sd, p + ".branch1_bn"), (1, stride, stride), dtype)
+        return hh.to_ncdhw(out)
     if (p + ".branch1.weight") in sd:
         sc = hh.conv_bn_act(x, sd[p + ".branch1.weight"], *hh.fold_bn(sd, p + ".branch1_bn"), (1, stride, stride),
                             (0, 0, 0), False, dtype)
@@ -87,6 +91,17 @@ def test_golden_kats(golden_f3, dtype):
             want = want.to(hh.TORCH_DT[dtype]).float()          # max-pool of rounded inputs is exact
         got = run_hip_kat(case, dtype)
         _close(got, want, dtype, case["name"], scale=3.0 if case["kind"] in ("block", "stem") else 1.0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_projection_block_unfused_path(golden_f3, dtype):
+    """the same blocks with the shortcut as its own launch + residual add (generic path of af_conv3d_bn_act)"""
+    cases, arrays = golden_f3
+    for case in cases:
+        if case["kind"] == "block" and "proj" in case["name"]:
+            sd, x = _kat_state(case), _kat_input(case)
+            got = hip_block(x, sd, case["name"], case["stride"], dtype, fuse_shortcut=False)
+            _close(got, torch.from_numpy(arrays[case["name"] + "_out"]), dtype, case["name"], scale=3.0)
 
 
 def test_fold_bn_matches_torch():
