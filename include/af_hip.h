@@ -55,6 +55,9 @@ typedef struct af_conv_desc {
     int32_t to, ho, wo;             /* output [n][to][ho][wo][cout]; checked */
     int32_t relu;                   /* ReLU after scale/shift(+residual)     */
     int32_t dtype;                  /* af_dtype of in / weights / residual / out */
+    int32_t tpool;                  /* 1: also apply MaxPool3d([2,1,1],stride [2,1,1]) (pathway0_pool,
+                                       video_model_builder.py:474-480) to the result: out is then
+                                       [n][to/2][ho][wo][cout]; to must be even (af_conv3d_bn_act only) */
 } af_conv_desc;
 
 typedef struct af_pool_desc {

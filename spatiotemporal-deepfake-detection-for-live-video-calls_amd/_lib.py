@@ -17,7 +17,7 @@ DTYPE_CODES = {"f32": AF_F32, "bf16": AF_BF16, "f16": AF_F16}
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "n", "t", "h", "w", "cin", "cout", "kt", "kh", "kw", "st", "sh", "sw", "pt", "ph", "pw",
-        "to", "ho", "wo", "relu", "dtype")]
+        "to", "ho", "wo", "relu", "dtype", "tpool")]
 
 
 class PoolDesc(C.Structure):

@@ -34,6 +34,7 @@ struct ConvArgs {
     int kt, kh, kw, st, sh, sw, pt, ph, pw;
     int To, Ho, Wo;
     int relu, out_ld;
+    int tpool;          // fuse MaxPool3d([2,1,1],[2,1,1]) over output frame pairs into the epilogue
     long long M;        // N*To*Ho*Wo
     int tiles_n;        // Cout / BN
     int kpt;            // K-steps per tap = Cin / BK
@@ -106,9 +107,14 @@ __global__ __launch_bounds__(512, MINW) void conv_igemm_kernel(const ConvArgs a)
         xptr[i] = a.in;
         x2ptr[i] = a.in;
         if (m < a.M) {
-            int wo = (int)(m % a.Wo); long long t1 = m / a.Wo;
+            // tile row -> output position.  With the temporal pool fused, rows are ordered (n, to/2, ho, wo, to%2):
+            // the two frames a pool window spans are ADJACENT rows of the tile (the epilogue takes their max)
+            const long long mq = a.tpool ? (m >> 1) : m;
+            int wo = (int)(mq % a.Wo); long long t1 = mq / a.Wo;
             int ho = (int)(t1 % a.Ho); long long t2 = t1 / a.Ho;
-            int to = (int)(t2 % a.To); long long n = t2 / a.To;
+            const int tdiv = a.tpool ? (a.To >> 1) : a.To;
+            int to = (int)(t2 % tdiv); long long n = t2 / tdiv;
+            if (a.tpool) to = 2 * to + (int)(m & 1);
             const int ti0 = to * a.st - a.pt, hi0 = ho * a.sh - a.ph, wi0 = wo * a.sw - a.pw;
             xptr[i] = a.in + ((((n * a.T + ti0) * a.H + hi0) * a.W + wi0) * a.Cin + chunk * EPC) * ES;
             xmask[i] = 1u << 31;
@@ -317,32 +323,72 @@ __global__ __launch_bounds__(512, MINW) void conv_igemm_kernel(const ConvArgs a)
                 *reinterpret_cast<f32x4*>(patch + (j * 16 + frow) * PROW + chl) = acc[i][hf * TMH + j] * sc + sf;
         }
         __builtin_amdgcn_wave_barrier();               // same-wave LDS ops complete in order; keep the order
+        if (a.tpool) {
+            // rows (2r, 2r+1) = frames (2j, 2j+1) of one pixel: residual add + ReLU each, then the max -> pooled row
 #pragma unroll
-        for (int it = 0; it < PROWS / RPI; ++it) {
-            const int row = it * RPI + rr;
-            const long long m = m0 + wm * WTM + hf * PROWS + row;
-            float v[EPC];
+            for (int it = 0; it < PROWS / (2 * RPI); ++it) {
+                const int prow = it * RPI + rr;
+                const long long m = m0 + wm * WTM + hf * PROWS + 2 * prow;      // even row of the pair
+                float v[2][EPC];
 #pragma unroll
-            for (int e = 0; e < EPC; e += 4) {
-                const f32x4 t = *reinterpret_cast<const f32x4*>(patch + row * PROW + cc + e);
-                v[e] = t[0]; v[e + 1] = t[1]; v[e + 2] = t[2]; v[e + 3] = t[3];
+                for (int p2 = 0; p2 < 2; ++p2)
+#pragma unroll
+                    for (int e = 0; e < EPC; e += 4) {
+                        const f32x4 t = *reinterpret_cast<const f32x4*>(patch + (2 * prow + p2) * PROW + cc + e);
+                        v[p2][e] = t[0]; v[p2][e + 1] = t[1]; v[p2][e + 2] = t[2]; v[p2][e + 3] = t[3];
+                    }
+                if (m < a.M) {
+                    if (a.res) {
+                        const long long mq = m >> 1, hw = (long long)a.Ho * a.Wo;
+                        const long long pix = mq % hw, nj = mq / hw;               // nj = n * (To/2) + j
+                        const long long lin0 = (nj * 2) * hw + pix;                // (n, 2j, ho, wo) in NDHWC order
+#pragma unroll
+                        for (int p2 = 0; p2 < 2; ++p2) {
+                            const uint4 rraw = *reinterpret_cast<const uint4*>(a.res + ((lin0 + p2 * hw) * a.Cout + ch0) * ES);
+                            const typename E::type* re = reinterpret_cast<const typename E::type*>(&rraw);
+#pragma unroll
+                            for (int e = 0; e < EPC; ++e) v[p2][e] += E::to_f32(re[e]);
+                        }
+                    }
+                    uint4 o;
+                    typename E::type* oe = reinterpret_cast<typename E::type*>(&o);
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) {
+                        float x0 = v[0][e], x1 = v[1][e];
+                        if (a.relu) { x0 = fmaxf(x0, 0.f); x1 = fmaxf(x1, 0.f); }
+                        oe[e] = E::from_f32((x1 > x0 || x1 != x1) ? x1 : x0);      // NaN propagates like ATen's max_pool
+                    }
+                    *reinterpret_cast<uint4*>(a.out + ((m >> 1) * a.out_ld + ch0) * ES) = o;
+                }
             }
-            if (m < a.M) {
-                if (a.res) {
-                    const uint4 rraw = *reinterpret_cast<const uint4*>(a.res + (m * a.Cout + ch0) * ES);
-                    const typename E::type* re = reinterpret_cast<const typename E::type*>(&rraw);
+        } else {
 #pragma unroll
-                    for (int e = 0; e < EPC; ++e) v[e] += E::to_f32(re[e]);
+            for (int it = 0; it < PROWS / RPI; ++it) {
+                const int row = it * RPI + rr;
+                const long long m = m0 + wm * WTM + hf * PROWS + row;
+                float v[EPC];
+    #pragma unroll
+                for (int e = 0; e < EPC; e += 4) {
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(patch + row * PROW + cc + e);
+                    v[e] = t[0]; v[e + 1] = t[1]; v[e + 2] = t[2]; v[e + 3] = t[3];
                 }
-                if (a.relu) {
-#pragma unroll
-                    for (int e = 0; e < EPC; ++e) v[e] = fmaxf(v[e], 0.f);
+                if (m < a.M) {
+                    if (a.res) {
+                        const uint4 rraw = *reinterpret_cast<const uint4*>(a.res + (m * a.Cout + ch0) * ES);
+                        const typename E::type* re = reinterpret_cast<const typename E::type*>(&rraw);
+    #pragma unroll
+                        for (int e = 0; e < EPC; ++e) v[e] += E::to_f32(re[e]);
+                    }
+                    if (a.relu) {
+    #pragma unroll
+                        for (int e = 0; e < EPC; ++e) v[e] = fmaxf(v[e], 0.f);
+                    }
+                    uint4 o;
+                    typename E::type* oe = reinterpret_cast<typename E::type*>(&o);
+    #pragma unroll
+                    for (int e = 0; e < EPC; ++e) oe[e] = E::from_f32(v[e]);
+                    *reinterpret_cast<uint4*>(a.out + (m * a.out_ld + ch0) * ES) = o;
                 }
-                uint4 o;
-                typename E::type* oe = reinterpret_cast<typename E::type*>(&o);
-#pragma unroll
-                for (int e = 0; e < EPC; ++e) oe[e] = E::from_f32(v[e]);
-                *reinterpret_cast<uint4*>(a.out + (m * a.out_ld + ch0) * ES) = o;
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -450,6 +496,8 @@ static int conv_common(const af_conv_desc* d, const void* in, const void* w_pack
     a.kt = d->kt; a.kh = d->kh; a.kw = d->kw; a.st = d->st; a.sh = d->sh; a.sw = d->sw;
     a.pt = d->pt; a.ph = d->ph; a.pw = d->pw; a.To = to; a.Ho = ho; a.Wo = wo;
     a.relu = d->relu; a.out_ld = out_ld;
+    a.tpool = d->tpool ? 1 : 0;
+    AF_REQUIRE(!a.tpool || (to % 2 == 0), "conv: fused temporal pool needs an even number of output frames (%d)", to);
     a.M = (long long)d->n * to * ho * wo;
     a.in2 = nullptr; a.w2 = (const char*)w_packed; a.T2 = a.H2 = a.W2 = 1; a.Cin2 = bk; a.st2 = a.sh2 = a.sw2 = 1; a.kpt2 = 0;
     if (d2) {

@@ -127,22 +127,27 @@ class Engine:
         plan.append(("pool", (spec.stem_pool, spec.stem.cout), d, d2, cur, nxt, None)); need(nxt, d2, spec.stem.cout)
         cur, nxt = nxt, cur
         d, c = d2, spec.stem.cout
+        p2 = spec.pool_after_s2
+        fuse_tpool = (tuple(p2.kernel), tuple(p2.stride), tuple(p2.pad)) == ((2, 1, 1), (2, 1, 1), (0, 0, 0))
         for si, stage in enumerate(spec.stages):
-            for blk in stage.blocks:
+            for bi, blk in enumerate(stage.blocks):
                 res = cur
                 da = blk.a.out_dims(*d)
                 plan.append(("conv", blk.a, d, da, cur, "A", None)); need("A", da, blk.a.cout)
                 db = blk.b.out_dims(*da)
                 plan.append(("conv", blk.b, da, db, "A", "B", None)); need("B", db, blk.b.cout)
                 dc = blk.c.out_dims(*db)
+                # the temporal max-pool after s2 rides in the epilogue of s2's last conv when it can
+                tp = fuse_tpool and si == 0 and bi == len(stage.blocks) - 1 and blk.branch1 is None and dc[0] % 2 == 0
+                dstore = (dc[0] // 2,) + tuple(dc[1:]) if tp else dc
                 if blk.branch1 is not None:      # c conv + projection shortcut in one launch; no shortcut tensor
                     assert blk.branch1.out_dims(*d) == dc
                     plan.append(("dual", (blk.c, blk.branch1, d), db, dc, "B", nxt, cur)); need(nxt, dc, blk.c.cout)
                 else:
-                    plan.append(("conv", blk.c, db, dc, "B", nxt, res)); need(nxt, dc, blk.c.cout)
+                    plan.append(("conv_tpool" if tp else "conv", blk.c, db, dc, "B", nxt, res)); need(nxt, dstore, blk.c.cout)
                 cur, nxt = nxt, cur
-                d, c = dc, blk.c.cout
-            if si == 0:
+                d, c = dstore, blk.c.cout
+            if si == 0 and not tp:
                 d2 = pool_out(d, spec.pool_after_s2)
                 plan.append(("pool", (spec.pool_after_s2, c), d, d2, cur, nxt, None)); need(nxt, d2, c)
                 cur, nxt = nxt, cur
@@ -177,9 +182,10 @@ class Engine:
             op = self.ops[i]
             op.in_ = self.buf[bi].data_ptr()
             op.out = self.buf[bo].data_ptr()
-            if kind in ("stem", "conv"):
+            if kind in ("stem", "conv", "conv_tpool"):
                 cv: ConvSpec = sp
                 op.kind = _lib.AF_OP_STEM if kind == "stem" else _lib.AF_OP_CONV
+                op.conv.tpool = 1 if kind == "conv_tpool" else 0
                 op.tag = TAG_STEM if kind == "stem" else _conv_tag(cv)
                 cd = op.conv
                 cd.n, (cd.t, cd.h, cd.w), cd.cin, cd.cout = batch, din, cv.cin, cv.cout
@@ -299,7 +305,7 @@ class Engine:
         """Output of op ``op_index`` as an (N,T,H,W,C) view of its buffer (valid until overwritten)."""
         op = self.ops[op_index]
         if op.kind in (_lib.AF_OP_STEM, _lib.AF_OP_CONV, _lib.AF_OP_CONV_DUAL):
-            shape = (op.conv.n, op.conv.to, op.conv.ho, op.conv.wo, op.conv.cout)
+            shape = (op.conv.n, op.conv.to // 2 if op.conv.tpool else op.conv.to, op.conv.ho, op.conv.wo, op.conv.cout)
         elif op.kind == _lib.AF_OP_MAXPOOL:
             shape = (op.pool.n, op.pool.to, op.pool.ho, op.pool.wo, op.pool.c)
         else:

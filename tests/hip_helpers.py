@@ -40,7 +40,7 @@ def fold_bn(sd, prefix):
     return scale, shift
 
 
-def conv_bn_act(x_ndhwc, w_oidhw, scale, shift, stride, pad, relu, dtype, residual=None, out=None, out_ld=0):
+def conv_bn_act(x_ndhwc, w_oidhw, scale, shift, stride, pad, relu, dtype, residual=None, out=None, out_ld=0, tpool=False):
     L = lib()
     code = L.DTYPE_CODES[dtype]
     n, t, h, w, cin = x_ndhwc.shape
@@ -52,13 +52,13 @@ def conv_bn_act(x_ndhwc, w_oidhw, scale, shift, stride, pad, relu, dtype, residu
     d.st, d.sh, d.sw = stride
     d.pt, d.ph, d.pw = pad
     d.to, d.ho, d.wo = [(a + 2 * p - k) // s + 1 for a, p, k, s in zip((t, h, w), pad, (kt, kh, kw), stride)]
-    d.relu, d.dtype = int(relu), code
+    d.relu, d.dtype, d.tpool = int(relu), code, int(tpool)
     wsrc = w_oidhw.float().cuda().contiguous()
     nbytes = L.lib.af_packed_conv_weight_bytes(cout, cin, kt, kh, kw, code)
     packed = torch.empty(nbytes // (4 if dtype == "f32" else 2), dtype=TORCH_DT[dtype], device="cuda")
     L.check(L.lib.af_pack_conv_weight(_p(wsrc), cout, cin, kt, kh, kw, code, _p(packed), _stream()), "pack_conv_weight")
     if out is None:
-        out = torch.empty((n, d.to, d.ho, d.wo, cout), dtype=TORCH_DT[dtype], device="cuda")
+        out = torch.empty((n, d.to // 2 if tpool else d.to, d.ho, d.wo, cout), dtype=TORCH_DT[dtype], device="cuda")
     L.check(L.lib.af_conv3d_bn_act(C.byref(d), _p(x_ndhwc), _p(packed), _p(scale), _p(shift), _p(residual), _p(out),
                                    out_ld, _stream()), "conv3d_bn_act")
     return out

@@ -157,6 +157,29 @@ def test_conv_vs_oracle(case, dtype):
     assert err <= tol * (want.abs().max().item() + 1e-9), "%s[%s] err %.3e" % (name, dtype, err)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cin,cout,dims", [(64, 256, (2, 6, 9, 7)), (64, 64, (1, 4, 5, 5))])
+def test_conv_with_fused_temporal_maxpool(dtype, cin, cout, dims):
+    """s2's last 1x1x1 (+ residual + ReLU) with pathway0_pool = MaxPool3d([2,1,1]) fused into its epilogue."""
+    seed = 4242 + cout
+    lay = [("w.weight", (cout, cin, 1, 1, 1), "float32"), ("bn.weight", (cout,), "float32"), ("bn.bias", (cout,), "float32"),
+           ("bn.running_mean", (cout,), "float32"), ("bn.running_var", (cout,), "float32")]
+    sd = synth.fill_layout(lay, seed)
+    x = synth.synthetic_tensor((dims[0], cin) + dims[1:], seed)
+    res = synth.synthetic_tensor((dims[0], cout) + dims[1:], seed + 1)
+    if dtype != "f32":
+        x, res = x.to(hh.TORCH_DT[dtype]).float(), res.to(hh.TORCH_DT[dtype]).float()
+        sd["w.weight"] = sd["w.weight"].to(hh.TORCH_DT[dtype]).float()
+    y = oracle.conv_bn_act(x.double(), sd["w.weight"].double(), {k: v.double() for k, v in sd.items()}, "bn", (1, 1, 1), (0, 0, 0), False)
+    want = F.max_pool3d(F.relu(y + res.double()), (2, 1, 1), (2, 1, 1))
+    got = hh.conv_bn_act(hh.to_ndhwc(x, dtype), sd["w.weight"], *hh.fold_bn(sd, "bn"), (1, 1, 1), (0, 0, 0), True, dtype,
+                         residual=hh.to_ndhwc(res, dtype), tpool=True)
+    got = hh.to_ncdhw(got).double()
+    assert got.shape == want.shape
+    tol = {"f32": 2e-6, "f16": 1.5e-3, "bf16": 1.2e-2}[dtype]
+    assert (got - want).abs().max().item() <= tol * want.abs().max().item()
+
+
 def test_conv_out_ld_writes_into_concat_buffer():
     """FuseFastToSlow concatenates by channel: the conv writes at a channel offset of a wider tensor."""
     dtype = "f32"

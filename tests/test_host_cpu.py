@@ -105,7 +105,7 @@ def test_c_abi_exports_every_declared_symbol():
         assert hasattr(_lib.lib, name)
     assert _lib.lib.af_version() == 1
     import ctypes as C
-    assert C.sizeof(_lib.ConvDesc) == 20 * 4 and C.sizeof(_lib.PoolDesc) == 18 * 4
+    assert C.sizeof(_lib.ConvDesc) == 21 * 4 and C.sizeof(_lib.PoolDesc) == 18 * 4
 
 
 def test_abi_rejects_bad_arguments_without_a_gpu():
