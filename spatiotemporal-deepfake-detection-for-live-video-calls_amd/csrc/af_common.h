@@ -11,6 +11,11 @@ namespace af {
 
 int set_error(int code, const char* fmt, ...);
 
+// af_conv133.hip: register-resident-weights 1x3x3 64->64 kernel (s2 `b` convs), 16-bit dtypes
+bool conv133_applies(const af_conv_desc* d, const void* residual, int out_ld);
+int conv133_run(const af_conv_desc* d, const void* in, const void* w_packed, const float* scale, const float* shift,
+                void* out, hipStream_t stream);
+
 #define AF_REQUIRE(cond, ...)                                    \
     do {                                                         \
         if (!(cond)) return af::set_error(AF_ERR_ARG, __VA_ARGS__); \

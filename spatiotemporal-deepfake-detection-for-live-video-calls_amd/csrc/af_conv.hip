@@ -424,9 +424,10 @@ static int launch(const ConvArgs& a, hipStream_t stream) {
 // MFMA-bound: biggest tile.  Short-K layers (<= 3 K-steps) are HBM-bound streams of input, residual and
 // output: half-height tiles with a trimmed ring so several workgroups share a CU and overlap each
 // other's load / store phases.
-enum { VAR_128x256 = 0, VAR_64x256 = 1, VAR_128x128 = 2, VAR_64x128 = 3, VAR_COUNT = 4 };
+enum { VAR_128x256 = 0, VAR_64x256 = 1, VAR_128x128 = 2, VAR_64x128 = 3, VAR_C133 = 4, VAR_COUNT = 5 };
 static const char* const kVariantNames[] = {"conv_igemm<BN=128,BM=256>", "conv_igemm<BN=64,BM=256>",
-                                            "conv_igemm<BN=128,BM=128>", "conv_igemm<BN=64,BM=128>"};
+                                            "conv_igemm<BN=128,BM=128>", "conv_igemm<BN=64,BM=128>",
+                                            "conv133_c64<weights in registers>"};
 
 static int pick_variant(int cout, int cin, int taps, int dtype, int cin2 = 0) {
     const int ksteps = (taps * cin + cin2) / (dtype == AF_F32 ? 32 : 64);
@@ -458,6 +459,7 @@ static int dispatch(ConvArgs& a, hipStream_t stream) {
 
 extern "C" int af_conv_variant(const af_conv_desc* d, const af_conv_desc* d2) {
     AF_REQUIRE(d && d->cout > 0 && d->cin > 0 && af::dtype_ok(d->dtype), "conv_variant: bad descriptor");
+    if (!d2 && af::conv133_applies(d, nullptr, 0)) return af::VAR_C133;
     return af::pick_variant(d->cout, d->cin, d->kt * d->kh * d->kw, d->dtype, d2 ? d2->cin : 0);
 }
 
@@ -488,6 +490,9 @@ static int conv_common(const af_conv_desc* d, const void* in, const void* w_pack
     AF_REQUIRE((long long)d->cout * d->kt * d->kh * d->kw * d->cin < (1LL << 31), "conv: weight too large");
     AF_REQUIRE(d->kt * d->kh * d->kw <= 31, "conv: at most 31 kernel taps (got %d)", d->kt * d->kh * d->kw);
     AF_REQUIRE((long long)d->kt * d->h * d->w * d->cin * dtype_size(d->dtype) < (1LL << 31), "conv: tap offset overflows");
+
+    if (!d2 && conv133_applies(d, residual, out_ld))
+        return conv133_run(d, in, w_packed, scale, shift, out, (hipStream_t)stream);
 
     ConvArgs a;
     a.in = (const char*)in; a.w = (const char*)w_packed; a.scale = scale; a.shift = shift;

@@ -1,0 +1,206 @@
+// 1x3x3 / stride 1 / pad (0,1,1) convolution, 64 -> 64 channels, 16-bit operands: the `b` conv of the three
+// s2 bottlenecks (reference altfreezing/slowfast/models/resnet_helper.py:283-297), + BN + ReLU.
+//
+// The generic implicit GEMM streams every activation row through LDS once PER TAP (9x) and re-reads the
+// weight tile from LDS for every 32 positions; at Cin = Cout = 64 that makes the layer ingest / LDS bound
+// (~0.37 PFLOP/s).  This kernel is shaped around what is small here:
+//   * the whole weight tensor (64 x 9 x 64) lives in REGISTERS: a wave owns 32 output channels and keeps its
+//     36 MFMA A-fragments (9 taps x 2 k-halves x 2 channel tiles = 144 VGPRs) for the life of the workgroup;
+//     the A operand never touches LDS;
+//   * a workgroup walks a contiguous run of image strips (R = 4 output rows); each strip's input patch
+//     ((R+2) rows, zero halo columns included) is brought in ONCE by LDS-DMA, double-buffered under the MFMAs
+//     of the previous strip, and all 9 taps read it: with the rows stored at a padded pitch WP = W + 2 a tap
+//     (dh,dw) is the constant row offset dh*WP + dw, so every B fragment is a plain swizzled ds_read_b128;
+//   * positions are the padded strip (R x WP, two halo columns per row computed and discarded: 3.4 % waste).
+// Persistent: one workgroup per CU, one barrier per strip (~2 300 MFMA cycles per wave between barriers).
+#include "af_common.h"
+
+namespace af {
+
+__device__ uint4 g_zero_page_c133[8];         // 128 bytes of zeros: source of halo / out-of-image pixels
+
+struct C133Args {
+    const char* in;
+    const char* w;       // packed [64][9][64]
+    const float* scale;
+    const float* shift;
+    char* out;
+    int H, W, frames;
+    int strips_per_frame, total_strips;
+    int rows_alloc;      // LDS rows per patch buffer (multiple of 8)
+};
+
+__device__ __forceinline__ void glds16_c133(const void* gsrc, unsigned lds_base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_base) : "memory");
+}
+
+template <int DT, int R>
+__global__ __launch_bounds__(512, 2) void conv133_c64_kernel(const C133Args a) {
+    typedef Elem<DT> E;
+    static_assert(E::EPC == 8, "16-bit operands only");
+    constexpr int MT = 4;                              // m-tiles per wave (up to 16 per strip)
+    constexpr int PROW = 36;                           // epilogue patch row stride (floats): 32 channels + pad
+
+    extern __shared__ uint4 smem[];
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nh = wave & 1, mg = wave >> 1;           // channel half, m-tile group
+    const int frow = lane & 15, fg = lane >> 4;
+    const int WP = a.W + 2;
+    const int NT = (R * WP + 15) >> 4;                 // m-tiles per strip (<= 16, host-checked)
+    const int NP = a.rows_alloc >> 3;                  // DMA pieces per patch
+    const int buf_bytes = a.rows_alloc * 128;
+    float* patch = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + 2 * buf_bytes) + wave * (16 * PROW);
+
+    // ---- weights -> registers (A operand: lane = (channel row, k-group))
+    uint4 wreg[9][2][2];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int ch = nh * 32 + i * 16 + frow;
+                wreg[tap][kk][i] = *reinterpret_cast<const uint4*>(a.w + ((ch * 9 + tap) * 64 + kk * 32 + fg * 8) * 2);
+            }
+    f32x4 sc[2], sf[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        sc[i] = *reinterpret_cast<const f32x4*>(a.scale + nh * 32 + i * 16 + fg * 4);
+        sf[i] = *reinterpret_cast<const f32x4*>(a.shift + nh * 32 + i * 16 + fg * 4);
+    }
+
+    const char* zero = reinterpret_cast<const char*>(g_zero_page_c133);
+    const int dma_row = lane >> 3, dma_chunk = (lane & 7) ^ dma_row;      // LDS row inside a piece; source chunk
+    // patch LDS row j <-> padded pixel q = j - 1 : (r, c') = (q / WP, q % WP), input pixel (h0 + r - 1, c' - 1)
+    auto issue_patch = [&](int strip, int buf) {
+        const int frame = strip / a.strips_per_frame;
+        const int h0 = (strip - frame * a.strips_per_frame) * R;
+        const char* fbase = a.in + (long long)frame * a.H * a.W * 128 + dma_chunk * 16;
+        for (int g = wave; g < NP; g += 8) {
+            const int q = g * 8 + dma_row - 1;
+            const int r = q / WP, c = q - r * WP;
+            const int hi = h0 + r - 1;
+            const bool ok = q >= 0 && r < R + 2 && c >= 1 && c <= a.W && (unsigned)hi < (unsigned)a.H;
+            const char* src = ok ? fbase + ((long long)hi * a.W + (c - 1)) * 128 : zero;
+            glds16_c133(src, __builtin_amdgcn_readfirstlane(lds0 + buf * buf_bytes + g * 1024));   // provably wave-uniform
+        }
+    };
+
+    // contiguous run of strips for this workgroup
+    const int G = gridDim.x, b = blockIdx.x;
+    const int s0 = (int)((long long)a.total_strips * b / G), s1 = (int)((long long)a.total_strips * (b + 1) / G);
+    if (s0 < s1) issue_patch(s0, 0);
+
+    for (int s = s0; s < s1; ++s) {
+        const int buf = (s - s0) & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's pieces of strip s have landed
+        __builtin_amdgcn_s_barrier();                             // ... everybody's; and buffer buf^1 is no longer read
+        if (s + 1 < s1) issue_patch(s + 1, buf ^ 1);
+
+        const char* xb = reinterpret_cast<const char*>(smem) + buf * buf_bytes;
+        f32x4 acc[2][MT];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int k = 0; k < MT; ++k) acc[i][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dh = 0; dh < 3; ++dh)
+#pragma unroll
+            for (int dw = 0; dw < 3; ++dw) {
+                const int off = dh * WP + dw;                     // tap = constant row offset in the padded patch
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int k = 0; k < MT; ++k) {
+                        const int t = mg + 4 * k;
+                        if (t < NT) {
+                            const int row = t * 16 + frow + off;
+                            const uint4 bf = *reinterpret_cast<const uint4*>(xb + row * 128 + (((kk * 4 + fg) ^ (row & 7)) << 4));
+                            Mma<DT>::run(wreg[dh * 3 + dw][kk][0], bf, acc[0][k]);
+                            Mma<DT>::run(wreg[dh * 3 + dw][kk][1], bf, acc[1][k]);
+                        }
+                    }
+            }
+
+        // ---- epilogue: BN + ReLU, one m-tile at a time through a wave-private fp32 patch -> 16-byte stores
+        const int frame = s / a.strips_per_frame;
+        const int h0 = (s - frame * a.strips_per_frame) * R;
+        const int prow = lane >> 2, pcc = (lane & 3) * 8;
+#pragma unroll
+        for (int k = 0; k < MT; ++k) {
+            const int t = mg + 4 * k;
+            if (t < NT) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    f32x4 v = acc[i][k] * sc[i] + sf[i];
+                    v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+                    *reinterpret_cast<f32x4*>(patch + frow * PROW + i * 16 + fg * 4) = v;
+                }
+                __builtin_amdgcn_wave_barrier();
+                const int p = t * 16 + prow;
+                const int r = p / WP, c = p - r * WP;
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(patch + prow * PROW + pcc);
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(patch + prow * PROW + pcc + 4);
+                if (r < R && c >= 1 && c <= a.W && h0 + r < a.H) {
+                    uint4 o;
+                    typename E::type* oe = reinterpret_cast<typename E::type*>(&o);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { oe[e] = E::from_f32(v0[e]); oe[4 + e] = E::from_f32(v1[e]); }
+                    *reinterpret_cast<uint4*>(a.out + (((long long)frame * a.H + h0 + r) * a.W + (c - 1)) * 128 + (nh * 32 + pcc) * 2) = o;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+}
+
+static int g_num_cus = 0;
+
+template <int DT>
+static int launch_c133(C133Args& a, hipStream_t stream) {
+    constexpr int R = 4;
+    if (g_num_cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
+            return set_error(AF_ERR_LAUNCH, "conv133: cannot query the device");
+        g_num_cus = prop.multiProcessorCount;
+    }
+    const int WP = a.W + 2;
+    a.strips_per_frame = (a.H + R - 1) / R;
+    a.total_strips = a.frames * a.strips_per_frame;
+    a.rows_alloc = (((R + 2) * WP + 2 + 16) + 7) & ~7;
+    const int lds = 2 * a.rows_alloc * 128 + 8 * 16 * 36 * 4;
+    const int grid = a.total_strips < g_num_cus ? a.total_strips : g_num_cus;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv133_c64_kernel<DT, R>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return set_error(AF_ERR_LAUNCH, "conv133: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv133_c64_kernel<DT, R>), dim3(grid), dim3(512), lds, stream, a);
+    AF_CHECK_LAUNCH("conv133_c64_kernel");
+    return AF_OK;
+}
+
+// true iff this layer takes the register-resident-weights path (also used by af_conv_variant)
+bool conv133_applies(const af_conv_desc* d, const void* residual, int out_ld) {
+    return d->dtype != AF_F32 && d->cin == 64 && d->cout == 64 && d->kt == 1 && d->kh == 3 && d->kw == 3 &&
+           d->st == 1 && d->sh == 1 && d->sw == 1 && d->pt == 0 && d->ph == 1 && d->pw == 1 && d->relu && !d->tpool &&
+           residual == nullptr && (out_ld == 0 || out_ld == 64) && 4 * (d->w + 2) <= 256;
+}
+
+int conv133_run(const af_conv_desc* d, const void* in, const void* w_packed, const float* scale, const float* shift,
+                void* out, hipStream_t stream) {
+    C133Args a;
+    a.in = (const char*)in; a.w = (const char*)w_packed; a.scale = scale; a.shift = shift; a.out = (char*)out;
+    a.H = d->h; a.W = d->w; a.frames = d->n * d->t;
+    return d->dtype == AF_BF16 ? launch_c133<AF_BF16>(a, stream) : launch_c133<AF_F16>(a, stream);
+}
+
+}  // namespace af
