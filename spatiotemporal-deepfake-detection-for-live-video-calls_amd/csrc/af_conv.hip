@@ -34,6 +34,7 @@ struct ConvArgs {
     int kt, kh, kw, st, sh, sw, pt, ph, pw;
     int To, Ho, Wo;
     int relu, out_ld;
+    int ring;           // LDS ring slots used by the lean K loop: 3, or 2 (mid-K HBM-bound layers: 2 workgroups per CU)
     int tpool;          // fuse MaxPool3d([2,1,1],[2,1,1]) over output frame pairs into the epilogue
     long long M;        // N*To*Ho*Wo
     int tiles_n;        // Cout / BN
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(512, MINW) void conv_igemm_kernel(const ConvArgs a)
 
     const int S = taps * a.kpt + (DUAL ? a.kpt2 : 0);
     issue_stage(0);
-    if (S > 1) issue_stage(1);
+    if (S > 1 && !(LEAN && a.ring == 2)) issue_stage(1);
 
     const int frow = lane & 15, fg = lane >> 4;
     constexpr int NKK = 2 / KS;                                   // k-halves of a stage this wave multiplies
@@ -191,15 +192,9 @@ __global__ __launch_bounds__(512, MINW) void conv_igemm_kernel(const ConvArgs a)
     if (LEAN || NKK == 1 || TM < 4) {
         // HBM-bound short-K variants (and the K-split layout): smallest register footprint, one barrier per
         // K-step, all DMA pieces of stage s+2 issued right after it.
-        int st = 0;
-        for (int s = 0; s < S; ++s) {
-            // stage s has landed for this wave once only the younger stage (s+1) is still in flight ...
-            if (s + 1 < S) wait_vmcnt<PER_WAVE>(); else wait_vmcnt<0>();
-            // ... and for every wave after the barrier, which also retires all reads of slot (s-1)%3
-            __builtin_amdgcn_s_barrier();
-            if (s + 2 < S) issue_stage(st == 0 ? 2 : st - 1);    // slot (s+2)%3 == (s-1)%3 is free now
-            const uint4* ws = smem + st * (STAGE_BYTES / 16) + wrow;
-            const uint4* xs = smem + st * (STAGE_BYTES / 16) + xrow;
+        auto multiply = [&](int st_) {
+            const uint4* ws = smem + st_ * (STAGE_BYTES / 16) + wrow;
+            const uint4* xs = smem + st_ * (STAGE_BYTES / 16) + xrow;
 #pragma unroll
             for (int q = 0; q < NKK; ++q) {
                 const int c = ((kk0 + q) * 4 + fg) ^ (frow & 7);
@@ -213,7 +208,27 @@ __global__ __launch_bounds__(512, MINW) void conv_igemm_kernel(const ConvArgs a)
 #pragma unroll
                     for (int j = 0; j < TM; ++j) Mma<DT>::run(af[i], bf[j], acc[i][j]);
             }
-            st = (st == 2) ? 0 : st + 1;
+        };
+        if (LEAN && a.ring == 2) {
+            // two slots, one K-step of look-ahead: half the LDS, so two workgroups share a CU and cover each
+            // other's load / epilogue phases (4..8-step layers that stream a wide output)
+            for (int s = 0; s < S; ++s) {
+                wait_vmcnt<0>();                                  // stage s (the only one in flight) has landed
+                __builtin_amdgcn_s_barrier();                     // ... for everyone; slot (s+1)&1 is no longer read
+                if (s + 1 < S) issue_stage((s + 1) & 1);
+                multiply(s & 1);
+            }
+        } else {
+            int st = 0;
+            for (int s = 0; s < S; ++s) {
+                // stage s has landed for this wave once only the younger stage (s+1) is still in flight ...
+                if (s + 1 < S) wait_vmcnt<PER_WAVE>(); else wait_vmcnt<0>();
+                // ... and for every wave after the barrier, which also retires all reads of slot (s-1)%3
+                __builtin_amdgcn_s_barrier();
+                if (s + 2 < S) issue_stage(st == 0 ? 2 : st - 1);    // slot (s+2)%3 == (s-1)%3 is free now
+                multiply(st);
+                st = (st == 2) ? 0 : st + 1;
+            }
         }
     } else {
         // MFMA-bound variants: software-pipelined by k-HALVES.  The fragments of a half are read from LDS while
@@ -406,7 +421,8 @@ static int launch(const ConvArgs& a, hipStream_t stream) {
     constexpr int red_bytes = KS == 2 ? WN * WM * (BN / WN / 16) * TMv * 64 * 16 : 0;
     constexpr int patch_bytes = red_bytes + WN * WM * ((TMv >= 2 ? TMv / 2 : TMv) * 16) * (BN / WN + 4) * 4;
     const int S = a.kt * a.kh * a.kw * a.kpt + a.kpt2;
-    const int ring_bytes = (S < NSTAGE ? S : NSTAGE) * (BN + BM) * 128;
+    const int slots = (MINW >= 4 && a.ring == 2) ? 2 : NSTAGE;
+    const int ring_bytes = (S < slots ? S : slots) * (BN + BM) * 128;
     const int lds = ring_bytes > patch_bytes ? ring_bytes : patch_bytes;
     static bool attr_set = false;
     if (!attr_set) {
@@ -424,14 +440,15 @@ static int launch(const ConvArgs& a, hipStream_t stream) {
 // MFMA-bound: biggest tile.  Short-K layers (<= 3 K-steps) are HBM-bound streams of input, residual and
 // output: half-height tiles with a trimmed ring so several workgroups share a CU and overlap each
 // other's load / store phases.
-enum { VAR_128x256 = 0, VAR_64x256 = 1, VAR_128x128 = 2, VAR_64x128 = 3, VAR_C133 = 4, VAR_COUNT = 5 };
+enum { VAR_128x256 = 0, VAR_64x256 = 1, VAR_128x128 = 2, VAR_64x128 = 3, VAR_C133 = 4, VAR_128x128_R2 = 5, VAR_COUNT = 6 };
 static const char* const kVariantNames[] = {"conv_igemm<BN=128,BM=256>", "conv_igemm<BN=64,BM=256>",
                                             "conv_igemm<BN=128,BM=128>", "conv_igemm<BN=64,BM=128>",
-                                            "conv133_c64<weights in registers>"};
+                                            "conv133_c64<weights in registers>", "conv_igemm<BN=128,BM=128>"};
 
 static int pick_variant(int cout, int cin, int taps, int dtype, int cin2 = 0) {
     const int ksteps = (taps * cin + cin2) / (dtype == AF_F32 ? 32 : 64);
     const bool wide = cout % 128 == 0, short_k = ksteps <= 3;
+    if (wide && !short_k && ksteps <= 8 && cout >= 512) return VAR_128x128_R2;   // wide-output streams, 4..8 K-steps
     return wide ? (short_k ? VAR_128x128 : VAR_128x256) : (short_k ? VAR_64x128 : VAR_64x256);
 }
 
@@ -441,16 +458,18 @@ static int dispatch(ConvArgs& a, hipStream_t stream) {
     a.kpt = a.Cin / BK;
     a.kpt2 = a.in2 ? a.Cin2 / BK : 0;
     const int v = pick_variant(a.Cout, a.Cin, a.kt * a.kh * a.kw, DT, a.in2 ? a.Cin2 : 0);
-    a.tiles_n = a.Cout / ((v == VAR_128x256 || v == VAR_128x128) ? 128 : 64);
+    a.tiles_n = a.Cout / ((v == VAR_128x256 || v == VAR_128x128 || v == VAR_128x128_R2) ? 128 : 64);
+    a.ring = v == VAR_128x128_R2 ? 2 : 3;
     if (a.in2) {                                 // projection blocks: cout is a multiple of 256
         if (v == VAR_128x256) return launch<DT, 128, 256, 2, 4, 1, 2, true>(a, stream);
-        if (v == VAR_128x128) return launch<DT, 128, 128, 2, 4, 1, 6, true>(a, stream);
+        if (v == VAR_128x128 || v == VAR_128x128_R2) return launch<DT, 128, 128, 2, 4, 1, 6, true>(a, stream);
         return set_error(AF_ERR_ARG, "conv_dual: cout must be a multiple of 128");
     }
     switch (v) {
         case VAR_128x256: return launch<DT, 128, 256, 2, 4, 1, 2, false>(a, stream);
         case VAR_64x256: return launch<DT, 64, 256, 1, 8, 1, 2, false>(a, stream);
-        case VAR_128x128: return launch<DT, 128, 128, 2, 4, 1, 6, false>(a, stream);
+        case VAR_128x128:
+        case VAR_128x128_R2: return launch<DT, 128, 128, 2, 4, 1, 6, false>(a, stream);
         default: return launch<DT, 64, 128, 1, 8, 1, 4, false>(a, stream);
     }
 }
