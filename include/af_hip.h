@@ -112,6 +112,13 @@ int af_pack_input_u8(const uint8_t* clips, int n, int t, int h, int w,
 int af_stem_conv_bn_relu(const af_conv_desc* d, const void* stem_in, const void* w_packed,
                          const float* scale, const float* shift, void* out, void* stream);
 
+/* The whole ResNetBasicStem (stem_helper.py:173-178) as one launch: conv + BN + ReLU +
+ * MaxPool3d([1,3,3],stride [1,2,2],pad [0,1,1]); out = [n][to][(ho-1)/2+1][(wo-1)/2+1][64] where (to,ho,wo) are
+ * the conv output dims in `d`.  16-bit dtypes only (all weight slices stay resident in LDS); the conv output
+ * tensor is never materialised. */
+int af_stem_conv_bn_relu_maxpool(const af_conv_desc* d, const void* stem_in, const void* w_packed,
+                                 const float* scale, const float* shift, void* out, void* stream);
+
 /* Conv3d(bias=False)+BN[+residual add][+ReLU] as one implicit-GEMM launch: the a/b/c convs of
  * BottleneckTransform (resnet_helper.py:267-325), the projection shortcut and the add+ReLU of
  * ResBlock (resnet_helper.py:411-444), FuseFastToSlow's conv_f2s+bn+relu (video_model_builder.py:121-143).
@@ -151,7 +158,7 @@ int af_avgpool_fc(const af_pool_desc* d, const void* in, const float* fc_w, cons
 /* ---- whole-forward op list ------------------------------------------------------------ */
 
 enum af_op_kind { AF_OP_STEM = 0, AF_OP_CONV = 1, AF_OP_MAXPOOL = 2, AF_OP_HEAD = 3,
-                  AF_OP_PACK_F32 = 4, AF_OP_PACK_U8 = 5, AF_OP_CONV_DUAL = 6 };
+                  AF_OP_PACK_F32 = 4, AF_OP_PACK_U8 = 5, AF_OP_CONV_DUAL = 6, AF_OP_STEM_POOL = 7 };
 
 typedef struct af_op {
     int32_t kind;                    /* af_op_kind */

@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AF_HIP_LIB") or os.path.join(HERE, "libafhip.so")   # override: kernel experiments
 
 AF_F32, AF_BF16, AF_F16 = 0, 1, 2
-AF_OP_STEM, AF_OP_CONV, AF_OP_MAXPOOL, AF_OP_HEAD, AF_OP_PACK_F32, AF_OP_PACK_U8, AF_OP_CONV_DUAL = range(7)
+AF_OP_STEM, AF_OP_CONV, AF_OP_MAXPOOL, AF_OP_HEAD, AF_OP_PACK_F32, AF_OP_PACK_U8, AF_OP_CONV_DUAL, AF_OP_STEM_POOL = range(8)
 AF_ABI_VERSION = 1
 STEM_PAD_T, STEM_PAD_H, STEM_PAD_W_LEFT, STEM_PAD_W_TOTAL, STEM_CPAD = 2, 3, 3, 8, 4
 
@@ -54,6 +54,7 @@ ABI = {
     "af_pack_input_u8": (C.c_int, [C.c_void_p] + [C.c_int] * 4 + [C.POINTER(C.c_float), C.POINTER(C.c_float),
                                                                   C.c_int, C.c_void_p, C.c_void_p]),
     "af_stem_conv_bn_relu": (C.c_int, [C.POINTER(ConvDesc)] + [C.c_void_p] * 6),
+    "af_stem_conv_bn_relu_maxpool": (C.c_int, [C.POINTER(ConvDesc)] + [C.c_void_p] * 6),
     "af_conv3d_bn_act": (C.c_int, [C.POINTER(ConvDesc)] + [C.c_void_p] * 6 + [C.c_int, C.c_void_p]),
     "af_conv3d_dual_bn_act": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_void_p, C.POINTER(ConvDesc)] + [C.c_void_p] * 5
                               + [C.c_int, C.c_void_p]),

@@ -19,6 +19,8 @@ static int run_one(const af_op& op, hipStream_t s) {
     switch (op.kind) {
         case AF_OP_STEM:
             return af_stem_conv_bn_relu(&op.conv, op.in, op.weight, op.scale, op.shift, op.out, s);
+        case AF_OP_STEM_POOL:
+            return af_stem_conv_bn_relu_maxpool(&op.conv, op.in, op.weight, op.scale, op.shift, op.out, s);
         case AF_OP_CONV:
             return af_conv3d_bn_act(&op.conv, op.in, op.weight, op.scale, op.shift, op.residual, op.out, op.out_ld, s);
         case AF_OP_CONV_DUAL:

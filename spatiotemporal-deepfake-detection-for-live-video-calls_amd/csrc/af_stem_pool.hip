@@ -1,0 +1,231 @@
+// Stem with the max-pool fused: Conv3d(3->64,[kt,7,7],s[1,2,2]) + BN + ReLU + MaxPool3d([1,3,3],s[1,2,2],p[0,1,1])
+// (reference altfreezing/slowfast/models/stem_helper.py:156-178) as ONE launch, 16-bit operands.
+//
+// A persistent workgroup owns one output frame (n, t) and streams its conv rows top to bottom, two at a time:
+//   * all kt*7 weight slices (64 x 1120, 143 KB in 16-bit) are loaded into LDS once per frame - the un-fused
+//     kernel re-fetches them for every 256 positions;
+//   * wave w owns the 16-column tile w of BOTH rows of the pair (2 m-tiles x 4 channel tiles): the 3-row
+//     vertical max of the pool is then lane-local - previous odd row (kept in registers), even row, odd row;
+//   * the vertically reduced row goes through a 14 KB LDS line, the horizontal 3-max + stride 2 is taken there
+//     and the pooled row leaves as whole 128-byte pixels.
+// The 64x32x112x112 conv output never exists in HBM (B=16: -822 MB written, -822 MB read, one launch less).
+// Activation fragments come straight from the padded stem input by aligned 16-byte loads (as in af_stem.hip).
+#include "af_common.h"
+
+namespace af {
+
+struct StemPoolArgs {
+    const char* in;      // padded input [N][T+4][H+6][W+8][4]
+    const char* w;       // packed [kt][7][4 chunks][64][16 B]
+    const float* scale;
+    const float* shift;
+    char* out;           // pooled [N][T][Hp][Wq][64]
+    int Tp, Hp, Wp;      // padded input dims
+    int kt;
+    int To, Ho, Wo;      // conv output dims
+    int Hq, Wq;          // pooled dims
+    int frames;          // N*To
+};
+
+template <int DT, int KT>
+__global__ __launch_bounds__(512, 2) void stem_pool_kernel(const StemPoolArgs a) {
+    typedef Elem<DT> E;
+    typedef typename E::type elem_t;
+    static_assert(E::EPC == 8, "16-bit operands only");
+    constexpr int KH = 7, NCH = 4, COUT = 64, TN = 4;
+    constexpr int PIXB = 8;                                    // bytes per padded input pixel (4 x 16 bit)
+
+    extern __shared__ uint4 smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int frow = lane & 15, fg = lane >> 4;
+    const int wchunks = KT * KH * NCH * COUT;                  // uint4 in the weight image
+    uint4* wl = smem;
+    elem_t* line = reinterpret_cast<elem_t*>(smem + wchunks);  // [Wo_tiles*16][64] vertically reduced conv row
+    const int ncol_tiles = (a.Wo + 15) >> 4;                   // <= 8 (host-checked)
+    const bool active = wave < ncol_tiles;
+
+    // weights -> LDS, once
+    const uint4* wsrc = reinterpret_cast<const uint4*>(a.w);
+    for (int i = tid; i < wchunks; i += 512) wl[i] = wsrc[i];
+
+    f32x4 sc[TN], sf[TN];
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+        sc[i] = *reinterpret_cast<const f32x4*>(a.scale + i * 16 + fg * 4);
+        sf[i] = *reinterpret_cast<const f32x4*>(a.shift + i * 16 + fg * 4);
+    }
+    const long long row_bytes = (long long)a.Wp * PIXB, plane_bytes = row_bytes * a.Hp;
+    int wo = wave * 16 + frow;
+    if (wo > a.Wo - 1) wo = a.Wo - 1;                          // clamp: loads stay inside the row, result discarded
+
+    for (int frame = blockIdx.x; frame < a.frames; frame += gridDim.x) {
+        const int n = frame / a.To, to = frame - n * a.To;
+        // padded coords of tap (0,0,0) for conv output (to, ho, wo): t = to, h = 2*ho, w = 2*wo
+        const char* fin = a.in + ((long long)(n * a.Tp + to) * a.Hp) * row_bytes + (long long)(2 * wo) * PIXB + fg * 16;
+        f32x4 prev[TN];                                        // conv row 2j-1 (post-ReLU); 0 == -inf after a ReLU
+#pragma unroll
+        for (int i = 0; i < TN; ++i) prev[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        __syncthreads();                                       // weights visible (first frame) / line free
+        uint4 b0[KH], b1[KH];                                  // current dt plane's fragments for conv rows 2j, 2j+1
+        if (active) {
+            const char* x1 = fin + (long long)(2 * (a.Ho > 1 ? 1 : 0)) * row_bytes;
+#pragma unroll
+            for (int dh = 0; dh < KH; ++dh) {
+                b0[dh] = *reinterpret_cast<const uint4*>(fin + dh * row_bytes);
+                b1[dh] = *reinterpret_cast<const uint4*>(x1 + dh * row_bytes);
+            }
+        }
+
+        for (int j = 0; j < a.Hq; ++j) {
+            f32x4 acc[2][TN];
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int i = 0; i < TN; ++i) acc[r][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (active) {
+                // activation fragments of one dt plane (7 kernel rows x 2 conv rows = 14 aligned 16-byte loads) are
+                // fetched a whole plane ahead of the MFMAs that use them - the last plane of a row pair prefetches
+                // the first plane of the next pair; everything is unrolled, so the "copy" is register renaming
+#pragma unroll
+                for (int dt = 0; dt < KT; ++dt) {
+                    uint4 n0[KH], n1[KH];
+                    const bool more = dt + 1 < KT || j + 1 < a.Hq;
+                    if (more) {
+                        const int jn = dt + 1 < KT ? j : j + 1, dtn = dt + 1 < KT ? dt + 1 : 0;
+                        const int h0n = 2 * jn, h1n = (2 * jn + 1 < a.Ho) ? 2 * jn + 1 : a.Ho - 1;
+                        const char* y0 = fin + (long long)(2 * h0n) * row_bytes + dtn * plane_bytes;
+                        const char* y1 = fin + (long long)(2 * h1n) * row_bytes + dtn * plane_bytes;
+#pragma unroll
+                        for (int dh = 0; dh < KH; ++dh) {
+                            n0[dh] = *reinterpret_cast<const uint4*>(y0 + dh * row_bytes);
+                            n1[dh] = *reinterpret_cast<const uint4*>(y1 + dh * row_bytes);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);         // keep the 14 loads AHEAD of this plane's MFMAs (hipcc sinks them otherwise)
+#pragma unroll
+                    for (int dh = 0; dh < KH; ++dh) {
+                        const uint4* wrow = wl + ((dt * KH + dh) * NCH + fg) * COUT + frow;
+#pragma unroll
+                        for (int i = 0; i < TN; ++i) {
+                            const uint4 af = wrow[i * 16];
+                            Mma<DT>::run(af, b0[dh], acc[0][i]);
+                            Mma<DT>::run(af, b1[dh], acc[1][i]);
+                        }
+                    }
+                    if (more) {
+#pragma unroll
+                        for (int dh = 0; dh < KH; ++dh) { b0[dh] = n0[dh]; b1[dh] = n1[dh]; }
+                    }
+                }
+            }
+            // BN + ReLU, vertical 3-max (rows 2j-1, 2j, 2j+1), keep the odd row for the next pair
+            const bool odd_ok = 2 * j + 1 < a.Ho;
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                f32x4 v0 = acc[0][i] * sc[i] + sf[i], v1 = acc[1][i] * sc[i] + sf[i];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v0[e] = fmaxf(v0[e], 0.f);
+                    v1[e] = odd_ok ? fmaxf(v1[e], 0.f) : 0.f;
+                    const float m = fmaxf(fmaxf(prev[i][e], v0[e]), v1[e]);
+                    prev[i][e] = v1[e];
+                    v0[e] = m;
+                }
+                if (active) {                                  // line[col][64 ch]: 4 consecutive channels per lane
+                    typedef elem_t e4 __attribute__((ext_vector_type(4)));
+                    e4 o;
+                    o[0] = E::from_f32(v0[0]); o[1] = E::from_f32(v0[1]); o[2] = E::from_f32(v0[2]); o[3] = E::from_f32(v0[3]);
+                    *reinterpret_cast<e4*>(line + (wave * 16 + frow) * COUT + i * 16 + fg * 4) = o;
+                }
+            }
+            __syncthreads();
+            // horizontal 3-max, stride 2: pooled col q <- conv cols 2q-1, 2q, 2q+1; 8 channels (16 B) per thread
+            for (int idx = tid; idx < a.Wq * 8; idx += 512) {
+                const int q = idx >> 3, ch = (idx & 7) * 8;
+                float m[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) m[e] = 0.f;
+#pragma unroll
+                for (int d = -1; d <= 1; ++d) {
+                    const int c = 2 * q + d;
+                    if (c >= 0 && c < a.Wo) {
+                        const uint4 raw = *reinterpret_cast<const uint4*>(line + c * COUT + ch);
+                        const elem_t* pe = reinterpret_cast<const elem_t*>(&raw);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], E::to_f32(pe[e]));
+                    }
+                }
+                uint4 o;
+                elem_t* oe = reinterpret_cast<elem_t*>(&o);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) oe[e] = E::from_f32(m[e]);
+                *reinterpret_cast<uint4*>(a.out + ((((long long)n * a.To + to) * a.Hq + j) * a.Wq + q) * (COUT * 2) + ch * 2) = o;
+            }
+            __syncthreads();                                   // line may be overwritten by the next row pair
+        }
+    }
+}
+
+static int g_cus = 0;
+
+template <int DT, int KT>
+static int launch_stem_pool_kt(const StemPoolArgs& a, hipStream_t stream) {
+    if (g_cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
+            return set_error(AF_ERR_LAUNCH, "stem_pool: cannot query the device");
+        g_cus = prop.multiProcessorCount;
+    }
+    const int lds = a.kt * 7 * 4 * 64 * 16 + ((a.Wo + 15) / 16) * 16 * 64 * 2;
+    if (lds > 160 * 1024) return set_error(AF_ERR_ARG, "stem_pool: %d bytes of LDS needed", lds);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_pool_kernel<DT, KT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return set_error(AF_ERR_LAUNCH, "stem_pool: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    const int grid = a.frames < g_cus ? a.frames : g_cus;     // one resident workgroup per CU; weights loaded once each
+    hipLaunchKernelGGL((stem_pool_kernel<DT, KT>), dim3(grid), dim3(512), lds, stream, a);
+    AF_CHECK_LAUNCH("stem_pool_kernel");
+    return AF_OK;
+}
+
+template <int DT>
+static int launch_stem_pool(const StemPoolArgs& a, hipStream_t stream) {
+    switch (a.kt) {
+        case 1: return launch_stem_pool_kt<DT, 1>(a, stream);
+        case 3: return launch_stem_pool_kt<DT, 3>(a, stream);
+        default: return launch_stem_pool_kt<DT, 5>(a, stream);
+    }
+}
+
+}  // namespace af
+
+extern "C" int af_stem_conv_bn_relu_maxpool(const af_conv_desc* d, const void* stem_in, const void* w_packed,
+                                            const float* scale, const float* shift, void* out, void* stream) {
+    using namespace af;
+    AF_REQUIRE(d && stem_in && w_packed && scale && shift && out, "stem_pool: null argument");
+    AF_REQUIRE(d->dtype == AF_BF16 || d->dtype == AF_F16, "stem_pool: 16-bit dtypes only (fp32 weights do not fit LDS)");
+    AF_REQUIRE(d->cin == 3 && d->cout == 64, "stem_pool: expects 3 -> 64 channels");
+    AF_REQUIRE(d->kh == 7 && d->kw == 7 && d->sh == 2 && d->sw == 2 && d->st == 1 && d->ph == 3 && d->pw == 3,
+               "stem_pool: expects a [kt,7,7] kernel, stride [1,2,2], pad [kt/2,3,3]");
+    AF_REQUIRE(d->kt >= 1 && d->kt <= 2 * AF_STEM_PAD_T + 1 && (d->kt & 1) && d->pt == d->kt / 2, "stem_pool: bad kt/pt");
+    AF_REQUIRE(d->n > 0 && d->t > 0 && d->h > 0 && d->w > 0, "stem_pool: bad dims");
+    const int to = d->t, ho = (d->h + 6 - 7) / 2 + 1, wo = (d->w + 6 - 7) / 2 + 1;
+    AF_REQUIRE(to == d->to && ho == d->ho && wo == d->wo, "stem_pool: conv output dims mismatch");
+    AF_REQUIRE(wo <= 128, "stem_pool: conv output width %d > 128", wo);
+    AF_REQUIRE(aligned16(stem_in) && aligned16(w_packed) && aligned16(scale) && aligned16(shift) && aligned16(out),
+               "stem_pool: buffers must be 16-byte aligned");
+    StemPoolArgs a;
+    a.in = (const char*)stem_in; a.w = (const char*)w_packed; a.scale = scale; a.shift = shift; a.out = (char*)out;
+    a.Tp = d->t + 2 * AF_STEM_PAD_T; a.Hp = d->h + 2 * AF_STEM_PAD_H; a.Wp = d->w + AF_STEM_PAD_W_TOTAL;
+    a.kt = d->kt; a.To = to; a.Ho = ho; a.Wo = wo;
+    a.Hq = (ho - 1) / 2 + 1; a.Wq = (wo - 1) / 2 + 1;
+    a.frames = d->n * to;
+    a.in += (long long)(AF_STEM_PAD_T - d->pt) * a.Hp * a.Wp * 4 * dtype_size(d->dtype);
+    hipStream_t s = (hipStream_t)stream;
+    return d->dtype == AF_BF16 ? launch_stem_pool<AF_BF16>(a, s) : launch_stem_pool<AF_F16>(a, s);
+}

@@ -122,10 +122,16 @@ class Engine:
 
         cur, nxt = "P0", "P1"
         d = spec.stem.out_dims(T, H, W)
-        plan.append(("stem", spec.stem, (T, H, W), d, "IN", cur, None)); need(cur, d, spec.stem.cout)
         d2 = pool_out(d, spec.stem_pool)
-        plan.append(("pool", (spec.stem_pool, spec.stem.cout), d, d2, cur, nxt, None)); need(nxt, d2, spec.stem.cout)
-        cur, nxt = nxt, cur
+        sp_ = spec.stem_pool
+        fuse_stem_pool = (self.dtype != "f32" and d[2] <= 128 and spec.stem.cout == 64 and
+                          (tuple(sp_.kernel), tuple(sp_.stride), tuple(sp_.pad)) == ((1, 3, 3), (1, 2, 2), (0, 1, 1)))
+        if fuse_stem_pool:        # conv + BN + ReLU + max-pool in one launch; the conv output never reaches HBM
+            plan.append(("stem_pool", spec.stem, (T, H, W), d, "IN", cur, None)); need(cur, d2, spec.stem.cout)
+        else:
+            plan.append(("stem", spec.stem, (T, H, W), d, "IN", cur, None)); need(cur, d, spec.stem.cout)
+            plan.append(("pool", (spec.stem_pool, spec.stem.cout), d, d2, cur, nxt, None)); need(nxt, d2, spec.stem.cout)
+            cur, nxt = nxt, cur
         d, c = d2, spec.stem.cout
         p2 = spec.pool_after_s2
         fuse_tpool = (tuple(p2.kernel), tuple(p2.stride), tuple(p2.pad)) == ((2, 1, 1), (2, 1, 1), (0, 0, 0))
@@ -182,11 +188,11 @@ class Engine:
             op = self.ops[i]
             op.in_ = self.buf[bi].data_ptr()
             op.out = self.buf[bo].data_ptr()
-            if kind in ("stem", "conv", "conv_tpool"):
+            if kind in ("stem", "stem_pool", "conv", "conv_tpool"):
                 cv: ConvSpec = sp
-                op.kind = _lib.AF_OP_STEM if kind == "stem" else _lib.AF_OP_CONV
+                op.kind = {"stem": _lib.AF_OP_STEM, "stem_pool": _lib.AF_OP_STEM_POOL}.get(kind, _lib.AF_OP_CONV)
                 op.conv.tpool = 1 if kind == "conv_tpool" else 0
-                op.tag = TAG_STEM if kind == "stem" else _conv_tag(cv)
+                op.tag = TAG_STEM if kind in ("stem", "stem_pool") else _conv_tag(cv)
                 cd = op.conv
                 cd.n, (cd.t, cd.h, cd.w), cd.cin, cd.cout = batch, din, cv.cin, cv.cout
                 cd.kt, cd.kh, cd.kw = cv.kernel
@@ -304,7 +310,9 @@ class Engine:
     def activation(self, op_index: int) -> torch.Tensor:
         """Output of op ``op_index`` as an (N,T,H,W,C) view of its buffer (valid until overwritten)."""
         op = self.ops[op_index]
-        if op.kind in (_lib.AF_OP_STEM, _lib.AF_OP_CONV, _lib.AF_OP_CONV_DUAL):
+        if op.kind == _lib.AF_OP_STEM_POOL:
+            shape = (op.conv.n, op.conv.to, (op.conv.ho - 1) // 2 + 1, (op.conv.wo - 1) // 2 + 1, op.conv.cout)
+        elif op.kind in (_lib.AF_OP_STEM, _lib.AF_OP_CONV, _lib.AF_OP_CONV_DUAL):
             shape = (op.conv.n, op.conv.to // 2 if op.conv.tpool else op.conv.to, op.conv.ho, op.conv.wo, op.conv.cout)
         elif op.kind == _lib.AF_OP_MAXPOOL:
             shape = (op.pool.n, op.pool.to, op.pool.ho, op.pool.wo, op.pool.c)

@@ -147,6 +147,28 @@ def stem_conv(stem_in, dims, w_oidhw, scale, shift, dtype):
     return out
 
 
+def stem_conv_pool(stem_in, dims, w_oidhw, scale, shift, dtype):
+    """conv + BN + ReLU + max-pool [1,3,3]/[1,2,2]/[0,1,1] as one launch (16-bit dtypes)."""
+    L = lib()
+    code = L.DTYPE_CODES[dtype]
+    n, t, h, w = dims
+    cout, _, kt, kh, kw = w_oidhw.shape
+    d = L.ConvDesc()
+    d.n, d.t, d.h, d.w, d.cin, d.cout = n, t, h, w, 3, cout
+    d.kt, d.kh, d.kw, d.st, d.sh, d.sw, d.pt, d.ph, d.pw = kt, kh, kw, 1, 2, 2, kt // 2, 3, 3
+    d.to, d.ho, d.wo = t, (h + 6 - 7) // 2 + 1, (w + 6 - 7) // 2 + 1
+    d.relu, d.dtype = 1, code
+    wsrc = w_oidhw.float().cuda().contiguous()
+    nbytes = L.lib.af_packed_stem_weight_bytes(cout, kt, kh, code)
+    packed = torch.empty(nbytes // 2, dtype=TORCH_DT[dtype], device="cuda")
+    L.check(L.lib.af_pack_stem_weight(_p(wsrc), cout, kt, kh, kw, code, _p(packed), _stream()), "pack_stem_weight")
+    out = torch.empty((n, d.to, (d.ho - 1) // 2 + 1, (d.wo - 1) // 2 + 1, cout), dtype=TORCH_DT[dtype], device="cuda")
+    L.check(L.lib.af_stem_conv_bn_relu_maxpool(C.byref(d), _p(stem_in), _p(packed), _p(scale), _p(shift), _p(out), _stream()),
+            "stem_conv_bn_relu_maxpool")
+    torch.cuda.current_stream().synchronize()
+    return out
+
+
 def maxpool(x_ndhwc, kernel, stride, pad, dtype):
     L = lib()
     n, t, h, w, c = x_ndhwc.shape

@@ -53,11 +53,16 @@ def hip_block(x_ncdhw, sd, p, stride, dtype, fuse_shortcut=True):
     return hh.to_ncdhw(out)
 
 
-def hip_stem(x_ncdhw, sd, p, dtype):
+def hip_stem(x_ncdhw, sd, p, dtype, fused=None):
     xd = x_ncdhw.cuda()
     n, _, t, h, w = xd.shape
     sin = hh.pack_input_f32(xd, dtype)
-    y = hh.stem_conv(sin, (n, t, h, w), sd[p + ".conv.weight"], *hh.fold_bn(sd, p + ".bn"), dtype)
+    scale, shift = hh.fold_bn(sd, p + ".bn")
+    if fused is None:
+        fused = dtype != "f32"                  # what the engine does: one launch for conv + BN + ReLU + pool
+    if fused:
+        return hh.to_ncdhw(hh.stem_conv_pool(sin, (n, t, h, w), sd[p + ".conv.weight"], scale, shift, dtype))
+    y = hh.stem_conv(sin, (n, t, h, w), sd[p + ".conv.weight"], scale, shift, dtype)
     y = hh.maxpool(y, (1, 3, 3), (1, 2, 2), (0, 1, 1), dtype)
     return hh.to_ncdhw(y)
 
@@ -91,6 +96,24 @@ def test_golden_kats(golden_f3, dtype):
             want = want.to(hh.TORCH_DT[dtype]).float()          # max-pool of rounded inputs is exact
         got = run_hip_kat(case, dtype)
         _close(got, want, dtype, case["name"], scale=3.0 if case["kind"] in ("block", "stem") else 1.0)
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+def test_stem_unfused_path_and_odd_sizes(golden_f3, dtype):
+    """16-bit stem as two launches (conv, pool) on the golden cases; and the fused launch on odd conv heights/widths
+    (last pooled row/column sees a 2-wide window) against the oracle."""
+    cases, arrays = golden_f3
+    for case in cases:
+        if case["kind"] == "stem":
+            got = hip_stem(_kat_input(case), _kat_state(case), case["name"], dtype, fused=False)
+            _close(got, torch.from_numpy(arrays[case["name"] + "_out"]), dtype, case["name"], scale=3.0)
+    lay = [("s.conv.weight", (64, 3, 5, 7, 7), "float32"), ("s.bn.weight", (64,), "float32"), ("s.bn.bias", (64,), "float32"),
+           ("s.bn.running_mean", (64,), "float32"), ("s.bn.running_var", (64,), "float32")]
+    sd = synth.fill_layout(lay, 91)
+    for shape in ((1, 3, 3, 33, 37), (2, 3, 2, 18, 70)):          # conv out 17x19 and 9x35
+        x = synth.synthetic_tensor(shape, 92 + shape[3])
+        want = oracle.stem(x, sd, "s")
+        _close(hip_stem(x, sd, "s", dtype, fused=True), want, dtype, "stem %s" % (shape,), scale=3.0)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
