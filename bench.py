@@ -83,10 +83,13 @@ def main():
     from af_mi355x.classifier import Classifier
     from af_mi355x.engine import TAG_NAMES
 
-    rank, local_rank, world = parallel.init()
+    # AF_BENCH_REHEARSAL=1: all ranks share cuda:0 and talk over gloo - lets the N>1 code path be rehearsed on a
+    # one-GPU box; never set by the driver (its ranks get one GPU each and RCCL)
+    rehearsal = os.environ.get("AF_BENCH_REHEARSAL") == "1"
+    rank, local_rank, world = parallel.init(backend="gloo" if rehearsal else None)
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", 0 if rehearsal else local_rank)
     torch.cuda.set_device(dev)
     B = args.batch
 
