@@ -79,9 +79,13 @@ int af_device_count(void);
 int af_fold_bn(const float* gamma, const float* beta, const float* mean, const float* var,
                float eps, int channels, float* scale, float* shift, void* stream);
 
-/* nn.Conv3d weight OIDHW fp32 -> [cout][kt*kh*kw][cin] in `dtype` (K-major rows for the
- * implicit GEMM).  Output bytes: af_packed_conv_weight_bytes(). */
+/* nn.Conv3d weight OIDHW fp32 -> [cout_pad][kt*kh*kw][cin_pad] in `dtype` (K-major rows for the implicit GEMM);
+ * cout is padded to a multiple of 64 rows and cin to the K-step (64 elements, fp32: 32) with zeros, so any
+ * channel count that is a multiple of 8 (fp32: 4) runs (SlowFast's 8/16/32/80/320-channel layers).
+ * Output bytes: af_packed_conv_weight_bytes().  The BN scale/shift arrays handed to the conv entry points must
+ * have af_padded_channels(cout) entries (padding = anything finite). */
 int64_t af_packed_conv_weight_bytes(int cout, int cin, int kt, int kh, int kw, int dtype);
+int af_padded_channels(int cout);
 int af_pack_conv_weight(const float* w_oidhw, int cout, int cin, int kt, int kh, int kw,
                         int dtype, void* packed, void* stream);
 /* same, with each output-channel row multiplied by row_scale[cout] in fp32 before the rounding to `dtype`
@@ -122,7 +126,7 @@ int af_stem_conv_bn_relu_maxpool(const af_conv_desc* d, const void* stem_in, con
 /* Conv3d(bias=False)+BN[+residual add][+ReLU] as one implicit-GEMM launch: the a/b/c convs of
  * BottleneckTransform (resnet_helper.py:267-325), the projection shortcut and the add+ReLU of
  * ResBlock (resnet_helper.py:411-444), FuseFastToSlow's conv_f2s+bn+relu (video_model_builder.py:121-143).
- * Requires cin % 64 == 0 (16-bit) or cin % 32 == 0 (fp32) and cout % 64 == 0.
+ * Requires cin % 8 == 0 and cout % 8 == 0 (fp32: % 4); scale/shift have af_padded_channels(cout) entries.
  * `residual` (NULL or [n][to][ho][wo][cout]) is added before the ReLU.
  * `out_ld` = channel stride of `out` rows in elements (>= cout; lets FuseFastToSlow write into
  * the concatenated slow tensor), 0 means cout. */

@@ -45,6 +45,7 @@ ABI = {
     "af_device_count": (C.c_int, []),
     "af_fold_bn": (C.c_int, [C.c_void_p] * 4 + [C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "af_packed_conv_weight_bytes": (C.c_int64, [C.c_int] * 6),
+    "af_padded_channels": (C.c_int, [C.c_int]),
     "af_pack_conv_weight": (C.c_int, [C.c_void_p] + [C.c_int] * 6 + [C.c_void_p, C.c_void_p]),
     "af_pack_conv_weight_scaled": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p, C.c_void_p]),
     "af_packed_stem_weight_bytes": (C.c_int64, [C.c_int] * 4),

@@ -31,6 +31,7 @@ struct ConvArgs {
     const char* res;
     char* out;
     int T, H, W, Cin, Cout;
+    int CinP, CoutP;    // Cin rounded up to the K-step (zero-padded weight columns), Cout rounded up to 64 (zero rows)
     int kt, kh, kw, st, sh, sw, pt, ph, pw;
     int To, Ho, Wo;
     int relu, out_ld;
@@ -43,7 +44,7 @@ struct ConvArgs {
     // positions - the projection shortcut of a res block, accumulated into the same tile (kpt2 == 0: none)
     const char* in2;
     const char* w2;
-    int T2, H2, W2, Cin2, st2, sh2, sw2, kpt2;
+    int T2, H2, W2, Cin2, Cin2P, st2, sh2, sw2, kpt2;
 };
 
 // 128 bytes of zeros in HBM: the source of every out-of-bounds (padding) tap, so that zero padding
@@ -131,13 +132,18 @@ __global__ __launch_bounds__(512, MINW) void conv_igemm_kernel(const ConvArgs a)
                     }
         }
     }
-    const long long Kw = (long long)taps * a.Cin;      // weight row length (elements)
+    const long long Kw = (long long)taps * a.CinP;     // weight row length (elements, zero-padded per tap)
+    // channel tails (Cin not a multiple of the K-step): this lane's 16-byte chunk of the LAST slab of a tap is
+    // real only below Cin; beyond it the lane fetches zeros (the weights there are zero columns as well)
+    constexpr int BKE = 8 * EPC;
+    const bool clast = chunk * EPC < a.Cin - (a.kpt - 1) * BKE;
+    const bool clast2 = DUAL && chunk * EPC < a.Cin2 - (a.kpt2 - 1) * BKE;
     const char* wptr[RW];
     const char* w2ptr[RW];
 #pragma unroll
     for (int i = 0; i < RW; ++i) {
         wptr[i] = a.w + ((tile_n * BN + lrow + 64 * i) * Kw + chunk * EPC) * ES;
-        w2ptr[i] = a.w2 + ((long long)(tile_n * BN + lrow + 64 * i) * a.Cin2 + chunk * EPC) * ES;
+        w2ptr[i] = a.w2 + ((long long)(tile_n * BN + lrow + 64 * i) * a.Cin2P + chunk * EPC) * ES;
     }
     const char* zero = reinterpret_cast<const char*>(g_zero_page);
 
@@ -152,13 +158,13 @@ __global__ __launch_bounds__(512, MINW) void conv_igemm_kernel(const ConvArgs a)
         if (DUAL && tap >= taps) {                               // second segment (projection shortcut)
             const int off2 = kc * 128;
             if (g < RW) glds16(w2ptr[g] + off2, base);
-            else glds16((xmask[g - RW] >> 31) ? x2ptr[g - RW] + off2 : zero, base);
+            else glds16(((xmask[g - RW] >> 31) && (kc + 1 < a.kpt2 || clast2)) ? x2ptr[g - RW] + off2 : zero, base);
         } else if (g < RW) {
-            glds16(wptr[g] + (long long)(tap * a.Cin * ES + kc * 128), base);
+            glds16(wptr[g] + (long long)(tap * a.CinP * ES + kc * 128), base);
         } else {
             const int xoff = ((dt * a.H + dh) * a.W + dw) * a.Cin * ES + kc * 128;   // < 2^31 (host-checked)
-            const char* src = ((xmask[g - RW] >> tap) & 1u) ? xptr[g - RW] + xoff : zero;
-            glds16(src, base);
+            const bool ok = ((xmask[g - RW] >> tap) & 1u) && (kc + 1 < a.kpt || clast);
+            glds16(ok ? xptr[g - RW] + xoff : zero, base);
         }
     };
     auto advance = [&]() {
@@ -352,7 +358,7 @@ __global__ __launch_bounds__(512, MINW) void conv_igemm_kernel(const ConvArgs a)
                         const f32x4 t = *reinterpret_cast<const f32x4*>(patch + (2 * prow + p2) * PROW + cc + e);
                         v[p2][e] = t[0]; v[p2][e + 1] = t[1]; v[p2][e + 2] = t[2]; v[p2][e + 3] = t[3];
                     }
-                if (m < a.M) {
+                if (m < a.M && ch0 < a.Cout) {
                     if (a.res) {
                         const long long mq = m >> 1, hw = (long long)a.Ho * a.Wo;
                         const long long pix = mq % hw, nj = mq / hw;               // nj = n * (To/2) + j
@@ -387,7 +393,7 @@ __global__ __launch_bounds__(512, MINW) void conv_igemm_kernel(const ConvArgs a)
                     const f32x4 t = *reinterpret_cast<const f32x4*>(patch + row * PROW + cc + e);
                     v[e] = t[0]; v[e + 1] = t[1]; v[e + 2] = t[2]; v[e + 3] = t[3];
                 }
-                if (m < a.M) {
+                if (m < a.M && ch0 < a.Cout) {          // channel groups beyond Cout are padding
                     if (a.res) {
                         const uint4 rraw = *reinterpret_cast<const uint4*>(a.res + (m * a.Cout + ch0) * ES);
                         const typename E::type* re = reinterpret_cast<const typename E::type*>(&rraw);
@@ -455,15 +461,18 @@ static int pick_variant(int cout, int cin, int taps, int dtype, int cin2 = 0) {
 template <int DT>
 static int dispatch(ConvArgs& a, hipStream_t stream) {
     constexpr int BK = 8 * Elem<DT>::EPC;
-    a.kpt = a.Cin / BK;
-    a.kpt2 = a.in2 ? a.Cin2 / BK : 0;
-    const int v = pick_variant(a.Cout, a.Cin, a.kt * a.kh * a.kw, DT, a.in2 ? a.Cin2 : 0);
-    a.tiles_n = a.Cout / ((v == VAR_128x256 || v == VAR_128x128 || v == VAR_128x128_R2) ? 128 : 64);
+    a.kpt = (a.Cin + BK - 1) / BK;
+    a.CinP = a.kpt * BK;
+    a.kpt2 = a.in2 ? (a.Cin2 + BK - 1) / BK : 0;
+    a.Cin2P = a.kpt2 * BK;
+    a.CoutP = (a.Cout + 63) / 64 * 64;
+    const int v = pick_variant(a.CoutP, a.CinP, a.kt * a.kh * a.kw, DT, a.in2 ? a.Cin2P : 0);
+    a.tiles_n = a.CoutP / ((v == VAR_128x256 || v == VAR_128x128 || v == VAR_128x128_R2) ? 128 : 64);
     a.ring = v == VAR_128x128_R2 ? 2 : 3;
     if (a.in2) {                                 // projection blocks: cout is a multiple of 256
         if (v == VAR_128x256) return launch<DT, 128, 256, 2, 4, 1, 2, true>(a, stream);
         if (v == VAR_128x128 || v == VAR_128x128_R2) return launch<DT, 128, 128, 2, 4, 1, 6, true>(a, stream);
-        return set_error(AF_ERR_ARG, "conv_dual: cout must be a multiple of 128");
+        return set_error(AF_ERR_ARG, "conv_dual: padded cout must be a multiple of 128");
     }
     switch (v) {
         case VAR_128x256: return launch<DT, 128, 256, 2, 4, 1, 2, false>(a, stream);
@@ -479,7 +488,9 @@ static int dispatch(ConvArgs& a, hipStream_t stream) {
 extern "C" int af_conv_variant(const af_conv_desc* d, const af_conv_desc* d2) {
     AF_REQUIRE(d && d->cout > 0 && d->cin > 0 && af::dtype_ok(d->dtype), "conv_variant: bad descriptor");
     if (!d2 && af::conv133_applies(d, nullptr, 0)) return af::VAR_C133;
-    return af::pick_variant(d->cout, d->cin, d->kt * d->kh * d->kw, d->dtype, d2 ? d2->cin : 0);
+    const int bk = d->dtype == AF_F32 ? 32 : 64;
+    return af::pick_variant((d->cout + 63) / 64 * 64, (d->cin + bk - 1) / bk * bk, d->kt * d->kh * d->kw, d->dtype,
+                            d2 ? (d2->cin + bk - 1) / bk * bk : 0);
 }
 
 extern "C" const char* af_conv_variant_name(int variant) {
@@ -499,14 +510,14 @@ static int conv_common(const af_conv_desc* d, const void* in, const void* w_pack
               wo = (d->w + 2 * d->pw - d->kw) / d->sw + 1;
     AF_REQUIRE(to == d->to && ho == d->ho && wo == d->wo && to > 0 && ho > 0 && wo > 0,
                "conv: output dims (%d,%d,%d) do not match the descriptor (%d,%d,%d)", to, ho, wo, d->to, d->ho, d->wo);
-    const int bk = d->dtype == AF_F32 ? 32 : 64;
-    AF_REQUIRE(d->cin % bk == 0, "conv: cin=%d must be a multiple of %d for this dtype", d->cin, bk);
-    AF_REQUIRE(d->cout % 64 == 0, "conv: cout=%d must be a multiple of 64", d->cout);
+    const int bk = d->dtype == AF_F32 ? 32 : 64, epc = d->dtype == AF_F32 ? 4 : 8;
+    AF_REQUIRE(d->cin % epc == 0, "conv: cin=%d must be a multiple of %d for this dtype", d->cin, epc);
+    AF_REQUIRE(d->cout % epc == 0, "conv: cout=%d must be a multiple of %d for this dtype", d->cout, epc);
     if (out_ld == 0) out_ld = d->cout;
     AF_REQUIRE(out_ld >= d->cout && out_ld % 8 == 0, "conv: bad out_ld %d", out_ld);
     AF_REQUIRE(aligned16(in) && aligned16(w_packed) && aligned16(scale) && aligned16(shift) && aligned16(out) &&
                    aligned16(residual), "conv: buffers must be 16-byte aligned");
-    AF_REQUIRE((long long)d->cout * d->kt * d->kh * d->kw * d->cin < (1LL << 31), "conv: weight too large");
+    AF_REQUIRE((long long)(d->cout + 63) * d->kt * d->kh * d->kw * (d->cin + bk) < (1LL << 31), "conv: weight too large");
     AF_REQUIRE(d->kt * d->kh * d->kw <= 31, "conv: at most 31 kernel taps (got %d)", d->kt * d->kh * d->kw);
     AF_REQUIRE((long long)d->kt * d->h * d->w * d->cin * dtype_size(d->dtype) < (1LL << 31), "conv: tap offset overflows");
 
@@ -523,7 +534,7 @@ static int conv_common(const af_conv_desc* d, const void* in, const void* w_pack
     a.tpool = d->tpool ? 1 : 0;
     AF_REQUIRE(!a.tpool || (to % 2 == 0), "conv: fused temporal pool needs an even number of output frames (%d)", to);
     a.M = (long long)d->n * to * ho * wo;
-    a.in2 = nullptr; a.w2 = (const char*)w_packed; a.T2 = a.H2 = a.W2 = 1; a.Cin2 = bk; a.st2 = a.sh2 = a.sw2 = 1; a.kpt2 = 0;
+    a.in2 = nullptr; a.w2 = (const char*)w_packed; a.T2 = a.H2 = a.W2 = 1; a.Cin2 = a.Cin2P = bk; a.st2 = a.sh2 = a.sw2 = 1; a.kpt2 = 0;
     if (d2) {
         AF_REQUIRE(in2 && w2_packed && aligned16(in2) && aligned16(w2_packed), "conv: second segment needs in2 / w2");
         AF_REQUIRE(d2->dtype == d->dtype && d2->n == d->n && d2->cout == d->cout, "conv: second segment dtype/n/cout mismatch");
@@ -531,7 +542,7 @@ static int conv_common(const af_conv_desc* d, const void* in, const void* w_pack
                    "conv: second segment must be a 1x1x1 convolution without padding");
         AF_REQUIRE(d2->st > 0 && d2->sh > 0 && d2->sw > 0 && (d2->t - 1) / d2->st + 1 == to && (d2->h - 1) / d2->sh + 1 == ho &&
                        (d2->w - 1) / d2->sw + 1 == wo, "conv: second segment does not land on the same output positions");
-        AF_REQUIRE(d2->cin > 0 && d2->cin % bk == 0, "conv: second segment cin=%d must be a multiple of %d", d2->cin, bk);
+        AF_REQUIRE(d2->cin > 0 && d2->cin % epc == 0, "conv: second segment cin=%d must be a multiple of %d", d2->cin, epc);
         a.in2 = (const char*)in2; a.w2 = (const char*)w2_packed;
         a.T2 = d2->t; a.H2 = d2->h; a.W2 = d2->w; a.Cin2 = d2->cin; a.st2 = d2->st; a.sh2 = d2->sh; a.sw2 = d2->sw;
     }

@@ -15,17 +15,20 @@ __global__ void fold_bn_kernel(const float* gamma, const float* beta, const floa
     }
 }
 
-// OIDHW fp32 -> [o][tap][i] in DT
+// OIDHW fp32 -> [o_pad][tap][i_pad] in DT: cout padded to 64 rows, cin to the K-step (64 / 32 elements); zeros
 template <int DT>
 __global__ void pack_conv_weight_kernel(const float* __restrict__ w, const float* __restrict__ row_scale, int cout,
-                                        int cin, int taps, typename Elem<DT>::type* __restrict__ out) {
+                                        int cin, int taps, int coutp, int cinp, typename Elem<DT>::type* __restrict__ out) {
     long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;      // over output elements
-    long long total = (long long)cout * taps * cin;
+    long long total = (long long)coutp * taps * cinp;
     if (idx >= total) return;
-    int i = (int)(idx % cin); long long r = idx / cin;
+    int i = (int)(idx % cinp); long long r = idx / cinp;
     int tap = (int)(r % taps); int o = (int)(r / taps);
-    float v = w[((long long)o * cin + i) * taps + tap];
-    if (row_scale) v *= row_scale[o];               // BN scale folded in fp32, before the one rounding
+    float v = 0.f;
+    if (o < cout && i < cin) {
+        v = w[((long long)o * cin + i) * taps + tap];
+        if (row_scale) v *= row_scale[o];           // BN scale folded in fp32, before the one rounding
+    }
     out[idx] = Elem<DT>::from_f32(v);
 }
 
@@ -96,22 +99,27 @@ extern "C" int af_fold_bn(const float* gamma, const float* beta, const float* me
     return AF_OK;
 }
 
+static inline int pad_cout(int cout) { return (cout + 63) / 64 * 64; }
+static inline int pad_cin(int cin, int dtype) { const int bk = dtype == AF_F32 ? 32 : 64; return (cin + bk - 1) / bk * bk; }
+
 extern "C" int64_t af_packed_conv_weight_bytes(int cout, int cin, int kt, int kh, int kw, int dtype) {
     if (!dtype_ok(dtype) || cout <= 0 || cin <= 0 || kt <= 0 || kh <= 0 || kw <= 0) return AF_ERR_ARG;
-    return (int64_t)cout * cin * kt * kh * kw * dtype_size(dtype);
+    return (int64_t)pad_cout(cout) * pad_cin(cin, dtype) * kt * kh * kw * dtype_size(dtype);
 }
+
+extern "C" int af_padded_channels(int cout) { return cout > 0 ? pad_cout(cout) : AF_ERR_ARG; }
 
 extern "C" int af_pack_conv_weight_scaled(const float* w, const float* row_scale, int cout, int cin, int kt, int kh,
                                           int kw, int dtype, void* packed, void* stream) {
     AF_REQUIRE(w && packed && dtype_ok(dtype) && cout > 0 && cin > 0 && kt > 0 && kh > 0 && kw > 0,
                "pack_conv_weight: bad argument");
-    const int taps = kt * kh * kw;
-    const long long total = (long long)cout * cin * taps;
+    const int taps = kt * kh * kw, coutp = pad_cout(cout), cinp = pad_cin(cin, dtype);
+    const long long total = (long long)coutp * cinp * taps;
     hipStream_t s = (hipStream_t)stream;
     dim3 g(grid_for(total, 256)), b(256);
-    if (dtype == AF_F32) hipLaunchKernelGGL((pack_conv_weight_kernel<AF_F32>), g, b, 0, s, w, row_scale, cout, cin, taps, (float*)packed);
-    else if (dtype == AF_BF16) hipLaunchKernelGGL((pack_conv_weight_kernel<AF_BF16>), g, b, 0, s, w, row_scale, cout, cin, taps, (__bf16*)packed);
-    else hipLaunchKernelGGL((pack_conv_weight_kernel<AF_F16>), g, b, 0, s, w, row_scale, cout, cin, taps, (_Float16*)packed);
+    if (dtype == AF_F32) hipLaunchKernelGGL((pack_conv_weight_kernel<AF_F32>), g, b, 0, s, w, row_scale, cout, cin, taps, coutp, cinp, (float*)packed);
+    else if (dtype == AF_BF16) hipLaunchKernelGGL((pack_conv_weight_kernel<AF_BF16>), g, b, 0, s, w, row_scale, cout, cin, taps, coutp, cinp, (__bf16*)packed);
+    else hipLaunchKernelGGL((pack_conv_weight_kernel<AF_F16>), g, b, 0, s, w, row_scale, cout, cin, taps, coutp, cinp, (_Float16*)packed);
     AF_CHECK_LAUNCH("pack_conv_weight_kernel");
     return AF_OK;
 }

@@ -59,8 +59,9 @@ class PackedWeights:
             assert tuple(w.shape) == cv.weight_shape, (cv.conv, tuple(w.shape), cv.weight_shape)
             bn = [state[cv.bn + s].detach().to(device=device, dtype=torch.float32).contiguous()
                   for s in (".weight", ".bias", ".running_mean", ".running_var")]
-            scale = torch.empty(cv.cout, dtype=torch.float32, device=device)
-            shift = torch.empty(cv.cout, dtype=torch.float32, device=device)
+            cpad = lib.af_padded_channels(cv.cout)           # kernels read scale/shift over the padded channel tile
+            scale = torch.zeros(cpad, dtype=torch.float32, device=device)
+            shift = torch.zeros(cpad, dtype=torch.float32, device=device)
             check(lib.af_fold_bn(_ptr(bn[0]), _ptr(bn[1]), _ptr(bn[2]), _ptr(bn[3]), BN_EPS, cv.cout,
                                  _ptr(scale), _ptr(shift), st), "af_fold_bn")
             kt, kh, kw = cv.kernel
@@ -91,7 +92,7 @@ class PackedWeights:
                                                          code, _ptr(packed), st), "af_pack_conv_weight_scaled")
                     self.w_folded[cv.conv] = packed
                 self.shift_sum[blk.c.conv] = (self.shift[blk.c.conv] + self.shift[blk.branch1.conv]).contiguous()
-                self.ones[blk.c.conv] = torch.ones(blk.c.cout, dtype=torch.float32, device=device)
+                self.ones[blk.c.conv] = torch.ones(lib.af_padded_channels(blk.c.cout), dtype=torch.float32, device=device)
         self.fc_w = state[spec.head + ".weight"].detach().to(device=device, dtype=torch.float32).contiguous()
         self.fc_b = state[spec.head + ".bias"].detach().to(device=device, dtype=torch.float32).contiguous()
         torch.cuda.current_stream(device).synchronize()      # sources may be freed by the caller

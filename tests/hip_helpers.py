@@ -34,8 +34,9 @@ def fold_bn(sd, prefix):
     L = lib()
     ts = [sd[prefix + s].float().cuda().contiguous() for s in (".weight", ".bias", ".running_mean", ".running_var")]
     c = ts[0].numel()
-    scale = torch.empty(c, device="cuda")
-    shift = torch.empty(c, device="cuda")
+    cpad = L.lib.af_padded_channels(c)            # the conv kernels read scale/shift over the padded channel tile
+    scale = torch.zeros(cpad, device="cuda")
+    shift = torch.zeros(cpad, device="cuda")
     L.check(L.lib.af_fold_bn(_p(ts[0]), _p(ts[1]), _p(ts[2]), _p(ts[3]), 1e-5, c, _p(scale), _p(shift), _stream()), "fold_bn")
     return scale, shift
 
@@ -93,7 +94,7 @@ def conv_dual(x_ndhwc, w_oidhw, bn, x2_ndhwc, w2_oidhw, bn2, stride2, dtype):
     d2.st, d2.sh, d2.sw = stride2
     d2.to, d2.ho, d2.wo, d2.relu, d2.dtype = t, h, w, 1, code
     out = torch.empty((n, t, h, w, cout), dtype=TORCH_DT[dtype], device="cuda")
-    ones = torch.ones(cout, device="cuda")
+    ones = torch.ones(L.lib.af_padded_channels(cout), device="cuda")
     # keep every device buffer referenced until the launch has been enqueued (the caching allocator would
     # otherwise hand the first packed weight's memory to the second)
     pw, pw2, shift_sum = _pack_scaled(w_oidhw, scale, dtype), _pack_scaled(w2_oidhw, scale2, dtype), (shift + shift2).contiguous()

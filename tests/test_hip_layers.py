@@ -133,7 +133,7 @@ def test_fold_bn_matches_torch():
     scale, shift = hh.fold_bn(sd, "bn")
     x = synth.synthetic_tensor((3, 256, 2, 2, 2), 78)
     want = F.batch_norm(x, sd["bn.running_mean"], sd["bn.running_var"], sd["bn.weight"], sd["bn.bias"], False, 0.1, 1e-5)
-    got = x * scale.cpu().view(1, -1, 1, 1, 1) + shift.cpu().view(1, -1, 1, 1, 1)
+    got = x * scale.cpu()[:256].view(1, -1, 1, 1, 1) + shift.cpu()[:256].view(1, -1, 1, 1, 1)
     assert (got - want).abs().max().item() <= 2e-6
 
 
@@ -148,6 +148,13 @@ CONV_CASES = [
     ("3x3x3_synthetic", 64, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 4, 9, 10), True, False),
     ("5x1x1_t_stride8", 64, 128, (5, 1, 1), (8, 1, 1), (2, 0, 0), (1, 32, 4, 5), True, False),
     ("big_m_tail", 64, 64, (1, 1, 1), (1, 1, 1), (0, 0, 0), (3, 7, 17, 19), False, False),
+    # SlowFast channel counts: not multiples of the 64-wide K-step / channel tile (padding + masks)
+    ("sf_slow_s2a_80", 80, 64, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 2, 9, 9), True, False),
+    ("sf_fast_8to8_3x1x1", 8, 8, (3, 1, 1), (1, 1, 1), (1, 0, 0), (1, 6, 7, 7), True, False),
+    ("sf_fast_8to32_res", 8, 32, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 3, 6, 5), True, True),
+    ("sf_fast_16_1x3x3_s2", 16, 16, (1, 3, 3), (1, 2, 2), (0, 1, 1), (1, 4, 11, 12), True, False),
+    ("sf_slow_320to128", 320, 128, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 2, 7, 8), True, False),
+    ("sf_fuse_32to64_t8", 32, 64, (5, 1, 1), (8, 1, 1), (2, 0, 0), (1, 32, 3, 4), True, False),
 ]
 
 
@@ -239,7 +246,7 @@ def test_argument_errors_are_reported():
     d = L.ConvDesc()
     rc = L.lib.af_conv3d_bn_act(C.byref(d), None, None, None, None, None, None, 0, None)
     assert rc == -1 and b"null" in L.lib.af_last_error()
-    x = torch.zeros((1, 1, 4, 4, 48), device="cuda")
+    x = torch.zeros((1, 1, 4, 4, 42), device="cuda")
     with pytest.raises(L.AfError, match="multiple of"):
-        hh.conv_bn_act(x, torch.zeros(64, 48, 1, 1, 1), torch.ones(64, device="cuda"), torch.zeros(64, device="cuda"),
+        hh.conv_bn_act(x, torch.zeros(64, 42, 1, 1, 1), torch.ones(64, device="cuda"), torch.zeros(64, device="cuda"),
                        (1, 1, 1), (0, 0, 0), False, "f32")
