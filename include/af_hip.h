@@ -65,6 +65,8 @@ typedef struct af_pool_desc {
     int32_t kt, kh, kw, st, sh, sw, pt, ph, pw;
     int32_t to, ho, wo;
     int32_t dtype;
+    int32_t out_ld;                 /* af_maxpool3d: channel stride of the output rows (0 = c); lets the Slow
+                                       pathway's pooled stem leave room for the lateral's channels */
 } af_pool_desc;
 
 int af_version(void);
@@ -159,10 +161,18 @@ int af_maxpool3d(const af_pool_desc* d, const void* in, void* out, void* stream)
 int af_avgpool_fc(const af_pool_desc* d, const void* in, const float* fc_w, const float* fc_b,
                   int num_classes, float* pooled, float* logits, void* stream);
 
+/* The two halves of the head separately, for multi-pathway heads (SlowFast: one AvgPool3d per pathway, pooled
+ * vectors concatenated by channel - head_helper.py:79-85 - then one Linear): af_avgpool writes row r of the pooled
+ * result at pooled[r * pooled_ld + 0 .. c) (pass `pooled + channel_offset` to concatenate);
+ * af_linear: y[r][k] = dot(x[r][0..in_features), w[k]) + b[k] on fp32. */
+int af_avgpool(const af_pool_desc* d, const void* in, float* pooled, int pooled_ld, void* stream);
+int af_linear(const float* x, const float* w, const float* b, int rows, int in_features, int out_features,
+              float* y, void* stream);
+
 /* ---- whole-forward op list ------------------------------------------------------------ */
 
 enum af_op_kind { AF_OP_STEM = 0, AF_OP_CONV = 1, AF_OP_MAXPOOL = 2, AF_OP_HEAD = 3,
-                  AF_OP_PACK_F32 = 4, AF_OP_PACK_U8 = 5, AF_OP_CONV_DUAL = 6, AF_OP_STEM_POOL = 7 };
+                  AF_OP_PACK_F32 = 4, AF_OP_PACK_U8 = 5, AF_OP_CONV_DUAL = 6, AF_OP_STEM_POOL = 7, AF_OP_AVGPOOL = 8, AF_OP_LINEAR = 9 };
 
 typedef struct af_op {
     int32_t kind;                    /* af_op_kind */

@@ -267,6 +267,70 @@ def gen_f4(clf):
                    "rows": rows}, f, indent=1)
 
 
+def gen_slowfast():
+    """F5: the reference's two-pathway SlowFast-R50 (video_model_builder.py:146-387).  No shipped plugin builds it;
+    it is instantiated here straight from the reference's own config defaults."""
+    ref_import.import_reference()
+    from slowfast.config.defaults import get_cfg
+    from slowfast.models.video_model_builder import SlowFast
+    cfg = get_cfg()
+    cfg.MODEL.ARCH = "slowfast"
+    cfg.MODEL.NUM_CLASSES = 1
+    cfg.DATA.NUM_FRAMES = 32
+    cfg.RESNET.NUM_BLOCK_TEMP_KERNEL = [[3, 3], [4, 4], [6, 6], [3, 3]]
+    cfg.RESNET.SPATIAL_STRIDES = [[1, 1], [2, 2], [2, 2], [2, 2]]
+    cfg.RESNET.SPATIAL_DILATIONS = [[1, 1]] * 4
+    cfg.NONLOCAL.LOCATION = [[[], []]] * 4
+    cfg.NONLOCAL.GROUP = [[1, 1]] * 4
+    net = SlowFast(cfg).eval()
+    spec = arch.slowfast_r50_spec()
+    lay = [("resnet." + k, list(v.shape), str(v.dtype).replace("torch.", "")) for k, v in net.state_dict().items()]
+    mine = [(k, list(sh), d) for k, sh, d in arch.state_dict_layout(spec)]
+    assert mine == lay, "product SlowFast table disagrees with the reference state_dict layout"
+    sd = synth.synthetic_state_dict(spec, seed=WEIGHT_SEED)
+    net.load_state_dict({k[len("resnet."):]: v for k, v in sd.items()})
+    alpha = cfg.SLOWFAST.ALPHA
+
+    stage_out, hooks = {}, []
+    for name in ("s1_fuse", "s2_fuse", "s3_fuse", "s4_fuse", "s5"):
+        def mk(n):
+            def hook(m, inp, out):
+                stage_out[n] = [o.detach().clone() for o in out]
+            return hook
+        hooks.append(getattr(net, name).register_forward_hook(mk(name)))
+    entries, f5 = [], {}
+    for ci, (kind, seed, index) in enumerate([("uniform", CLIP_SEED, 0), ("smooth", CLIP_SEED, 0)]):
+        u8 = synth.synthetic_clips_u8(index + 1, seed=seed, kind=kind)[index:index + 1]
+        x = synth.normalize_like_callers(u8)
+        with torch.no_grad():
+            y32 = net([x[:, :, ::alpha], x])
+        if ci == 0:
+            for n, (ts, tf) in stage_out.items():
+                for tag, t in (("slow", ts), ("fast", tf)):
+                    flat = t.flatten()
+                    idx = _sample_idx(flat.numel())
+                    f5["%s_%s_shape" % (n, tag)] = np.array(t.shape, dtype=np.int64)
+                    f5["%s_%s_absmean" % (n, tag)] = np.array([flat.double().abs().mean().item()])
+                    f5["%s_%s_idx" % (n, tag)] = idx.numpy()
+                    f5["%s_%s_val" % (n, tag)] = flat[idx].numpy()
+        net.double()
+        with torch.no_grad():
+            y64 = net([x[:, :, ::alpha].double(), x.double()])
+        net.float()
+        entries.append({"kind": kind, "seed": seed, "index": index, "clip_sha256": synth.tensor_sha256(u8),
+                        "logit_f32": float(y32[0, 0]), "logit_f64": float(y64[0, 0])})
+        print("F5 slowfast clip", kind, "logit f32 %.9g f64 %.12g" % (y32[0, 0].item(), y64[0, 0].item()))
+    for h in hooks:
+        h.remove()
+    with open(os.path.join(GOLD, "f5_slowfast.json"), "w") as f:
+        json.dump({"source": "reference slowfast.models.video_model_builder.SlowFast (R50, alpha 8, beta_inv 8), "
+                             "input [x[:,:,::8], x], PyTorch CPU, weights W(seed) in its state_dict layout",
+                   "num_keys": len(lay), "num_params": int(sum(p.numel() for p in net.parameters())),
+                   "alpha": alpha, "weights_seed": WEIGHT_SEED, "weights_sha256": synth.state_dict_sha256(sd),
+                   "clips": entries}, f, indent=1)
+    np.savez_compressed(os.path.join(GOLD, "f5_slowfast_stages.npz"), **f5)
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.manual_seed(0)
@@ -276,6 +340,7 @@ def main():
     gen_f3()
     gen_f4(clf)
     gen_f1_f2(clf)
+    gen_slowfast()
 
 
 if __name__ == "__main__":

@@ -109,6 +109,55 @@ def forward(sd, x, num_frames=32, crop=224, dtype=torch.float32, return_stages=F
     return logits
 
 
+# ---- two-pathway SlowFast (altfreezing/slowfast/models/video_model_builder.py:86-143, 146-387) ----------------
+
+def _stage_pathway(x, sd, stage, pathway):
+    stage_stride = 1 if stage == 2 else 2
+    i = 0
+    while ("resnet.s%d.pathway%d_res%d.branch2.a.weight" % (stage, pathway, i)) in sd:
+        x = res_block(x, sd, "resnet.s%d.pathway%d_res%d" % (stage, pathway, i), stage_stride if i == 0 else 1)
+        i += 1
+    return x
+
+
+def fuse_fast_to_slow(xs, xf, sd, p, alpha):
+    """FuseFastToSlow.forward: conv_f2s [k,1,1] stride [alpha,1,1] pad [k//2,0,0] + BN + ReLU on the Fast tensor,
+    concatenated to the Slow one by channel."""
+    w = sd[p + ".conv_f2s.weight"]
+    k = w.shape[2]
+    f = conv_bn_act(xf, w, sd, p + ".bn", (alpha, 1, 1), (k // 2, 0, 0), relu=True)
+    return torch.cat([xs, f], 1)
+
+
+def slowfast_forward(sd, x_slow, x_fast, alpha=8, dtype=torch.float32, return_stages=False):
+    """SlowFast.forward([x_slow, x_fast]) -> (B, num_classes * positions) logits."""
+    sd = {k: v for k, v in sd.items()}
+    xs, xf = x_slow.to(dtype), x_fast.to(dtype)
+    stages = OrderedDict()
+    with torch.no_grad():
+        xs = stem(xs, sd, "resnet.s1.pathway0_stem")
+        xf = stem(xf, sd, "resnet.s1.pathway1_stem")
+        xs = fuse_fast_to_slow(xs, xf, sd, "resnet.s1_fuse", alpha)
+        stages["s1"] = (xs, xf)
+        for st in (2, 3, 4, 5):
+            xs = _stage_pathway(xs, sd, st, 0)
+            xf = _stage_pathway(xf, sd, st, 1)
+            if st < 5:
+                xs = fuse_fast_to_slow(xs, xf, sd, "resnet.s%d_fuse" % st, alpha)
+            stages["s%d" % st] = (xs, xf)                          # pathway pools are [1,1,1]: identity
+        # head pools: [T/alpha, crop/32, crop/32] and [T, crop/32, crop/32] (video_model_builder.py:349-365)
+        t_fast = x_fast.shape[2]
+        crop32 = x_fast.shape[3] // 32
+        ps = F.avg_pool3d(xs, kernel_size=(t_fast // alpha, crop32, crop32), stride=1)
+        pf = F.avg_pool3d(xf, kernel_size=(t_fast, crop32, crop32), stride=1)
+        z = torch.cat([ps, pf], 1).permute(0, 2, 3, 4, 1)
+        z = F.linear(z, sd["resnet.head.projection.weight"].to(z.dtype), sd["resnet.head.projection.bias"].to(z.dtype))
+        logits = z.reshape(z.shape[0], -1)
+    if return_stages:
+        return logits, stages
+    return logits
+
+
 def normalize(clips_bthwc):
     """callers' pre-processing (af_realtime.py:77-83): (B,T,H,W,C) 0..255 -> (B,C,T,H,W) fp32."""
     x = torch.as_tensor(clips_bthwc, dtype=torch.float32).permute(0, 4, 1, 2, 3)

@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AF_HIP_LIB") or os.path.join(HERE, "libafhip.so")   # override: kernel experiments
 
 AF_F32, AF_BF16, AF_F16 = 0, 1, 2
-AF_OP_STEM, AF_OP_CONV, AF_OP_MAXPOOL, AF_OP_HEAD, AF_OP_PACK_F32, AF_OP_PACK_U8, AF_OP_CONV_DUAL, AF_OP_STEM_POOL = range(8)
+AF_OP_STEM, AF_OP_CONV, AF_OP_MAXPOOL, AF_OP_HEAD, AF_OP_PACK_F32, AF_OP_PACK_U8, AF_OP_CONV_DUAL, AF_OP_STEM_POOL, AF_OP_AVGPOOL, AF_OP_LINEAR = range(10)
 AF_ABI_VERSION = 1
 STEM_PAD_T, STEM_PAD_H, STEM_PAD_W_LEFT, STEM_PAD_W_TOTAL, STEM_CPAD = 2, 3, 3, 8, 4
 
@@ -22,7 +22,8 @@ class ConvDesc(C.Structure):
 
 class PoolDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
-        "n", "t", "h", "w", "c", "kt", "kh", "kw", "st", "sh", "sw", "pt", "ph", "pw", "to", "ho", "wo", "dtype")]
+        "n", "t", "h", "w", "c", "kt", "kh", "kw", "st", "sh", "sw", "pt", "ph", "pw", "to", "ho", "wo", "dtype",
+        "out_ld")]
 
 
 class Op(C.Structure):
@@ -63,6 +64,8 @@ ABI = {
     "af_conv_variant_name": (C.c_char_p, [C.c_int]),
     "af_maxpool3d": (C.c_int, [C.POINTER(PoolDesc), C.c_void_p, C.c_void_p, C.c_void_p]),
     "af_avgpool_fc": (C.c_int, [C.POINTER(PoolDesc)] + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 3),
+    "af_avgpool": (C.c_int, [C.POINTER(PoolDesc), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "af_linear": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p, C.c_void_p]),
     "af_run_ops": (C.c_int, [C.POINTER(Op), C.c_int, C.c_void_p]),
     "af_run_ops_timed": (C.c_int, [C.POINTER(Op), C.c_int, C.c_void_p, C.POINTER(C.c_float)]),
 }

@@ -151,9 +151,103 @@ def i3d_r50_spec(num_frames: int = 32, crop: int = 224) -> NetSpec:
         head_in=dim_in, num_classes=1)
 
 
-def state_dict_layout(spec: NetSpec):
+def _bottleneck_stage(sname: str, pathway: int, dim_in: int, dim_out: int, dim_inner: int, depth: int,
+                      stride: int, tks) -> StageSpec:
+    """ResStage of one pathway (resnet_helper.py:585-603): block 0 carries the stride and the projection."""
+    blocks = []
+    for bi in range(depth):
+        bname = "%s.pathway%d_res%d" % (sname, pathway, bi)
+        cin = dim_in if bi == 0 else dim_out
+        s = stride if bi == 0 else 1
+        tk = tks[bi]
+        branch1 = None
+        if cin != dim_out or s != 1:
+            branch1 = ConvSpec(bname + ".branch1", bname + ".branch1_bn", cin, dim_out, (1, 1, 1), (1, s, s), (0, 0, 0),
+                               relu=False)
+        a = ConvSpec(bname + ".branch2.a", bname + ".branch2.a_bn", cin, dim_inner, (tk, 1, 1), (1, 1, 1),
+                     (tk // 2, 0, 0), relu=True)
+        b = ConvSpec(bname + ".branch2.b", bname + ".branch2.b_bn", dim_inner, dim_inner, (1, 3, 3), (1, s, s),
+                     (0, 1, 1), relu=True)
+        c = ConvSpec(bname + ".branch2.c", bname + ".branch2.c_bn", dim_inner, dim_out, (1, 1, 1), (1, 1, 1),
+                     (0, 0, 0), relu=False, final_bn=True)
+        blocks.append(BlockSpec(bname, branch1, a, b, c))
+    return StageSpec(sname, tuple(blocks))
+
+
+@dataclass(frozen=True)
+class SlowFastSpec:
+    """Two-pathway SlowFast-R50 (reference video_model_builder.py:146-387; never instantiated by a shipped plugin).
+    Pathway 0 = Slow (every alpha-th frame, full width), pathway 1 = Fast (all frames, width / beta_inv).
+    After s1..s4 the Fast tensor is fused into the Slow one: Conv3d([5,1,1], stride [alpha,1,1]) + BN + ReLU,
+    concatenated by channel (FuseFastToSlow, :86-143)."""
+    num_frames: int
+    crop: int
+    alpha: int
+    stems: Tuple[ConvSpec, ConvSpec]
+    stem_pool: PoolSpec
+    fuses: Tuple[ConvSpec, ...]                       # after s1, s2, s3, s4
+    stages: Tuple[Tuple[StageSpec, StageSpec], ...]   # (slow, fast) for s2..s5
+    head_pools: Tuple[Tuple[int, int, int], Tuple[int, int, int]]
+    head_in: int
+    num_classes: int
+    head: str = "resnet.head.projection"
+
+    def convs(self) -> List[ConvSpec]:
+        """state_dict order: s1 (both stems), s1_fuse, s2 (slow blocks, then fast blocks), s2_fuse, ..."""
+        out = [self.stems[0], self.stems[1], self.fuses[0]]
+        for si, (slow, fast) in enumerate(self.stages):
+            for st in (slow, fast):
+                for blk in st.blocks:
+                    if blk.branch1 is not None:
+                        out.append(blk.branch1)
+                    out += [blk.a, blk.b, blk.c]
+            if si + 1 < len(self.fuses):
+                out.append(self.fuses[si + 1])
+        return out
+
+
+_SLOWFAST_TEMPORAL_BASIS = (((1,), (5,)), ((1,), (3,)), ((1,), (3,)), ((3,), (3,)), ((3,), (3,)))
+
+
+def slowfast_r50_spec(num_frames: int = 32, crop: int = 224, alpha: int = 8, beta_inv: int = 8,
+                      fusion_ratio: int = 2, fusion_kernel: int = 5) -> SlowFastSpec:
+    wf = _WIDTH // beta_inv
+    kt_s, kt_f = _SLOWFAST_TEMPORAL_BASIS[0][0][0], _SLOWFAST_TEMPORAL_BASIS[0][1][0]
+    stems = (ConvSpec("resnet.s1.pathway0_stem.conv", "resnet.s1.pathway0_stem.bn", 3, _WIDTH, (kt_s, 7, 7), (1, 2, 2),
+                      (kt_s // 2, 3, 3), relu=True),
+             ConvSpec("resnet.s1.pathway1_stem.conv", "resnet.s1.pathway1_stem.bn", 3, wf, (kt_f, 7, 7), (1, 2, 2),
+                      (kt_f // 2, 3, 3), relu=True))
+
+    def fuse(name, cfast):
+        return ConvSpec("resnet.%s.conv_f2s" % name, "resnet.%s.bn" % name, cfast, cfast * fusion_ratio,
+                        (fusion_kernel, 1, 1), (alpha, 1, 1), (fusion_kernel // 2, 0, 0), relu=True)
+
+    fuses = [fuse("s1_fuse", wf)]
+    stages = []
+    slow_in, fast_in = _WIDTH + wf * fusion_ratio, wf
+    for si, depth in enumerate(_STAGE_DEPTH_R50):
+        sname = "resnet.s%d" % (si + 2)
+        inner = _WIDTH * (2 ** si)
+        out = inner * 4
+        stride = 1 if si == 0 else 2
+        tk_s = _block_temporal_kernels(_SLOWFAST_TEMPORAL_BASIS[si + 1][0], depth, depth)
+        tk_f = _block_temporal_kernels(_SLOWFAST_TEMPORAL_BASIS[si + 1][1], depth, depth)
+        stages.append((_bottleneck_stage(sname, 0, slow_in, out, inner, depth, stride, tk_s),
+                       _bottleneck_stage(sname, 1, fast_in, out // beta_inv, inner // beta_inv, depth, stride, tk_f)))
+        if si < 3:
+            fuses.append(fuse("s%d_fuse" % (si + 2), out // beta_inv))
+        slow_in, fast_in = out + (out // beta_inv) * fusion_ratio, out // beta_inv
+    c_slow, c_fast = _WIDTH * 32, _WIDTH * 32 // beta_inv
+    return SlowFastSpec(
+        num_frames=num_frames, crop=crop, alpha=alpha, stems=stems,
+        stem_pool=PoolSpec((1, 3, 3), (1, 2, 2), (0, 1, 1)), fuses=tuple(fuses), stages=tuple(stages),
+        head_pools=((num_frames // alpha, crop // 32, crop // 32), (num_frames, crop // 32, crop // 32)),
+        head_in=c_slow + c_fast, num_classes=1)
+
+
+def state_dict_layout(spec):
     """[(key, shape, dtype_name)] in the reference's ``network.state_dict()`` order
-    (320 keys for the 32x224 config)."""
+    (320 keys for the i3d 32x224 config; 662 keys for SlowFast-R50)."""
     out = []
     for cv in spec.convs():
         out.append((cv.conv + ".weight", cv.weight_shape, "float32"))

@@ -26,7 +26,7 @@ from typing import Dict, Optional, Tuple
 import torch
 from torch import nn
 
-from .arch import ConvSpec, NetSpec, i3d_r50_spec
+from .arch import ConvSpec, NetSpec, i3d_r50_spec, slowfast_r50_spec
 
 logger = logging.getLogger("af_mi355x")
 
@@ -76,17 +76,15 @@ def _init_like_reference(root: nn.Module, fc_std: float = 0.01, zero_init_final_
             m.bias.data.zero_()
 
 
-class I3D8x8(nn.Module):
-    """The plugin's network module (``module_to_build`` of the reference Classifier)."""
+class _HipNetwork(nn.Module):
+    """Parameter skeleton (reference names / shapes, so state_dict / load_state_dict / .to behave as upstream)
+    + the HIP engine cache.  Subclasses define ``forward``."""
 
-    def __init__(self, clip_size: int = 32, imsize: int = 224, precision: str = "auto", crop_size: int = 224) -> None:
+    def __init__(self, spec, precision: str) -> None:
         super().__init__()
         if precision not in PRECISIONS:
             raise ValueError("precision must be one of %s" % (PRECISIONS,))
-        # the head pool is sized from DATA.CROP_SIZE=224 (defaults.py:277), not from imsize (SURVEY App. B);
-        # crop_size is only changed by tests that run a shrunken network
-        self.spec: NetSpec = i3d_r50_spec(num_frames=clip_size, crop=crop_size)
-        self.clip_size, self.imsize, self.precision = clip_size, imsize, precision
+        self.spec, self.precision = spec, precision
         self.resnet = _Node()
         for cv in self.spec.convs():
             _attach(self, cv.conv, _conv_module(cv))
@@ -125,9 +123,7 @@ class I3D8x8(nn.Module):
             self._engines[key] = Engine(self.spec, self._packed[dtype][1], batch, device, dims)
         return self._engines[key]
 
-    # -- forward ------------------------------------------------------------------------------------------
-    def forward(self, images, noise=None, has_mask=None, freeze_backbone=False, return_feature_maps=False):
-        assert not freeze_backbone
+    def _check_input(self, images):
         if not isinstance(images, torch.Tensor) or images.dim() != 5 or images.size(1) != 3:
             raise ValueError("images must be a (B,3,T,H,W) tensor")
         if not images.is_cuda:
@@ -135,13 +131,36 @@ class I3D8x8(nn.Module):
                                "got a tensor on %s" % images.device)
         if self.training:
             raise RuntimeError("inference only: call .eval() first (BatchNorm running statistics are folded)")
-        dev = images.device
-        if next(self.parameters()).device != dev:
-            raise RuntimeError("model parameters are on %s but the input is on %s" % (next(self.parameters()).device, dev))
-        x = images if images.dtype == torch.float32 else images.float()
+        if next(self.parameters()).device != images.device:
+            raise RuntimeError("model parameters are on %s but the input is on %s"
+                               % (next(self.parameters()).device, images.device))
+        return images if images.dtype == torch.float32 else images.float()
+
+    def _finish(self, eng, logits, pooled, B):
+        proj = self.resnet.head.projection
+        if proj._forward_hooks or proj._forward_pre_hooks:
+            # somebody (feature.py:105-114) listens on the head Linear: feed it the pooled feature in the
+            # reference's (N,T',H',W',C) layout so the hook sees the same input/output as upstream
+            feat = pooled.view((B,) + tuple(eng.head_dims) + (pooled.shape[-1],))
+            return proj(feat.clone()).reshape(B, -1)
+        return logits.clone().view(B, -1)
+
+
+class I3D8x8(_HipNetwork):
+    """The plugin's network module (``module_to_build`` of the reference Classifier)."""
+
+    def __init__(self, clip_size: int = 32, imsize: int = 224, precision: str = "auto", crop_size: int = 224) -> None:
+        # the head pool is sized from DATA.CROP_SIZE=224 (defaults.py:277), not from imsize (SURVEY App. B);
+        # crop_size is only changed by tests that run a shrunken network
+        super().__init__(i3d_r50_spec(num_frames=clip_size, crop=crop_size), precision)
+        self.clip_size, self.imsize = clip_size, imsize
+
+    def forward(self, images, noise=None, has_mask=None, freeze_backbone=False, return_feature_maps=False):
+        assert not freeze_backbone
+        x = self._check_input(images)
         B, _, T, H, W = x.shape
-        with torch.cuda.device(dev):
-            eng = self._engine(self._select_dtype(), B, (T, H, W), dev)
+        with torch.cuda.device(x.device):
+            eng = self._engine(self._select_dtype(), B, (T, H, W), x.device)
             logits, pooled = eng.run_f32(x)
             pred = self._finish(eng, logits, pooled, B)
         return {"final_output": pred}
@@ -161,14 +180,33 @@ class I3D8x8(nn.Module):
             pred = self._finish(eng, logits, pooled, B)
         return {"final_output": pred}
 
-    def _finish(self, eng, logits, pooled, B):
-        proj = self.resnet.head.projection
-        if proj._forward_hooks or proj._forward_pre_hooks:
-            # somebody (feature.py:105-114) listens on the head Linear: feed it the pooled feature in the
-            # reference's (N,T',H',W',C) layout so the hook sees the same input/output as upstream
-            feat = pooled.view((B,) + tuple(eng.head_dims) + (pooled.shape[-1],))
-            return proj(feat.clone()).reshape(B, -1)
-        return logits.clone().view(B, -1)
+
+class SlowFast8x8(_HipNetwork):
+    """Two-pathway SlowFast-R50 (reference slowfast/models/video_model_builder.py:146-387) on the same kernels:
+    the Fast->Slow laterals (FuseFastToSlow, :86-143) are strided temporal convs that write their channels straight
+    behind the Slow pathway's in the same NDHWC rows (no concat copy).  The reference ships no plugin that builds
+    it; the parameter names are those of its ``SlowFast`` module under a ``resnet.`` prefix like ``I3D8x8``.
+
+    ``forward(inputs)``: ``inputs = [slow, fast]`` exactly like ``SlowFast.forward`` (slow = T/alpha frames, fast = T
+    frames, both (B,3,t,H,W)); a single (B,3,T,H,W) clip is also accepted and read with a frame stride of alpha for
+    the Slow pathway."""
+
+    def __init__(self, clip_size: int = 32, precision: str = "auto", crop_size: int = 224, alpha: int = 8) -> None:
+        super().__init__(slowfast_r50_spec(num_frames=clip_size, crop=crop_size, alpha=alpha), precision)
+        self.clip_size = clip_size
+
+    def forward(self, inputs, bboxes=None):
+        xs = [inputs] if isinstance(inputs, torch.Tensor) else list(inputs)
+        if len(xs) not in (1, 2):
+            raise ValueError("SlowFast takes [slow, fast] (or one clip)")
+        xs = [self._check_input(x) for x in xs]
+        fast = xs[-1]
+        B, _, T, H, W = fast.shape
+        with torch.cuda.device(fast.device):
+            eng = self._engine(self._select_dtype(), B, (T, H, W), fast.device)
+            logits, pooled = eng.run_f32(*xs)
+            pred = self._finish(eng, logits, pooled, B)
+        return {"final_output": pred}
 
 
 def _unwrap_checkpoint(saved):

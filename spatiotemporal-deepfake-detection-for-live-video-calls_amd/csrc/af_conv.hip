@@ -469,10 +469,14 @@ static int dispatch(ConvArgs& a, hipStream_t stream) {
     const int v = pick_variant(a.CoutP, a.CinP, a.kt * a.kh * a.kw, DT, a.in2 ? a.Cin2P : 0);
     a.tiles_n = a.CoutP / ((v == VAR_128x256 || v == VAR_128x128 || v == VAR_128x128_R2) ? 128 : 64);
     a.ring = v == VAR_128x128_R2 ? 2 : 3;
-    if (a.in2) {                                 // projection blocks: cout is a multiple of 256
-        if (v == VAR_128x256) return launch<DT, 128, 256, 2, 4, 1, 2, true>(a, stream);
-        if (v == VAR_128x128 || v == VAR_128x128_R2) return launch<DT, 128, 128, 2, 4, 1, 6, true>(a, stream);
-        return set_error(AF_ERR_ARG, "conv_dual: padded cout must be a multiple of 128");
+    if (a.in2) {                                 // projection blocks (64-wide tiles: SlowFast's Fast pathway)
+        switch (v) {
+            case VAR_128x256: return launch<DT, 128, 256, 2, 4, 1, 2, true>(a, stream);
+            case VAR_64x256: return launch<DT, 64, 256, 1, 8, 1, 2, true>(a, stream);
+            case VAR_128x128:
+            case VAR_128x128_R2: return launch<DT, 128, 128, 2, 4, 1, 6, true>(a, stream);
+            default: return launch<DT, 64, 128, 1, 8, 1, 4, true>(a, stream);
+        }
     }
     switch (v) {
         case VAR_128x256: return launch<DT, 128, 256, 2, 4, 1, 2, false>(a, stream);

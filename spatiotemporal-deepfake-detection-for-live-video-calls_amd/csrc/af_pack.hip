@@ -34,21 +34,21 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, const float
 
 // (cout,3,kt,kh,7) fp32 -> [kt][kh][NCH][cout][EPC]: K-row (dt,dh) = 8 pixels x 4 channels, zero padded
 template <int DT>
-__global__ void pack_stem_weight_kernel(const float* __restrict__ w, int cout, int kt, int kh, int kw,
+__global__ void pack_stem_weight_kernel(const float* __restrict__ w, int cout, int coutp, int kt, int kh, int kw,
                                         typename Elem<DT>::type* __restrict__ out) {
     constexpr int EPC = Elem<DT>::EPC;
     constexpr int NCH = 32 / EPC;
     long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    long long total = (long long)kt * kh * NCH * cout * EPC;
+    long long total = (long long)kt * kh * NCH * coutp * EPC;
     if (idx >= total) return;
     int e = (int)(idx % EPC); long long r = idx / EPC;
-    int o = (int)(r % cout); r /= cout;
+    int o = (int)(r % coutp); r /= coutp;
     int ch = (int)(r % NCH); r /= NCH;
     int dh = (int)(r % kh); int dt = (int)(r / kh);
     int k = ch * EPC + e;               // 0..31 within the K-row
     int dw = k >> 2, c = k & 3;
     float v = 0.f;
-    if (dw < kw && c < 3) v = w[((((long long)o * 3 + c) * kt + dt) * kh + dh) * kw + dw];
+    if (dw < kw && c < 3 && o < cout) v = w[((((long long)o * 3 + c) * kt + dt) * kh + dh) * kw + dw];
     out[idx] = Elem<DT>::from_f32(v);
 }
 
@@ -129,21 +129,24 @@ extern "C" int af_pack_conv_weight(const float* w, int cout, int cin, int kt, in
     return af_pack_conv_weight_scaled(w, nullptr, cout, cin, kt, kh, kw, dtype, packed, stream);
 }
 
+static inline int pad_stem_cout(int cout) { return cout <= 16 ? 16 : 64; }     // channel tiles of the stem kernels
+
 extern "C" int64_t af_packed_stem_weight_bytes(int cout, int kt, int kh, int dtype) {
-    if (!dtype_ok(dtype) || cout <= 0 || kt <= 0 || kh <= 0) return AF_ERR_ARG;
-    return (int64_t)kt * kh * 32 * cout * dtype_size(dtype);
+    if (!dtype_ok(dtype) || cout <= 0 || cout > 64 || kt <= 0 || kh <= 0) return AF_ERR_ARG;
+    return (int64_t)kt * kh * 32 * pad_stem_cout(cout) * dtype_size(dtype);
 }
 
 extern "C" int af_pack_stem_weight(const float* w, int cout, int kt, int kh, int kw, int dtype, void* packed,
                                    void* stream) {
-    AF_REQUIRE(w && packed && dtype_ok(dtype) && cout > 0 && kt > 0 && kh > 0 && kw > 0 && kw <= 8,
+    AF_REQUIRE(w && packed && dtype_ok(dtype) && cout > 0 && cout <= 64 && kt > 0 && kh > 0 && kw > 0 && kw <= 8,
                "pack_stem_weight: bad argument");
-    const long long total = (long long)kt * kh * 32 * cout;
+    const int coutp = pad_stem_cout(cout);
+    const long long total = (long long)kt * kh * 32 * coutp;
     hipStream_t s = (hipStream_t)stream;
     dim3 g(grid_for(total, 256)), b(256);
-    if (dtype == AF_F32) hipLaunchKernelGGL((pack_stem_weight_kernel<AF_F32>), g, b, 0, s, w, cout, kt, kh, kw, (float*)packed);
-    else if (dtype == AF_BF16) hipLaunchKernelGGL((pack_stem_weight_kernel<AF_BF16>), g, b, 0, s, w, cout, kt, kh, kw, (__bf16*)packed);
-    else hipLaunchKernelGGL((pack_stem_weight_kernel<AF_F16>), g, b, 0, s, w, cout, kt, kh, kw, (_Float16*)packed);
+    if (dtype == AF_F32) hipLaunchKernelGGL((pack_stem_weight_kernel<AF_F32>), g, b, 0, s, w, cout, coutp, kt, kh, kw, (float*)packed);
+    else if (dtype == AF_BF16) hipLaunchKernelGGL((pack_stem_weight_kernel<AF_BF16>), g, b, 0, s, w, cout, coutp, kt, kh, kw, (__bf16*)packed);
+    else hipLaunchKernelGGL((pack_stem_weight_kernel<AF_F16>), g, b, 0, s, w, cout, coutp, kt, kh, kw, (_Float16*)packed);
     AF_CHECK_LAUNCH("pack_stem_weight_kernel");
     return AF_OK;
 }

@@ -9,6 +9,7 @@ struct PoolArgs {
     int T, H, W, C;
     int kt, kh, kw, st, sh, sw, pt, ph, pw;
     int To, Ho, Wo;
+    int out_ld;          // channel stride of the output rows
     long long total;     // N*To*Ho*Wo*(C/V)
 };
 
@@ -51,7 +52,7 @@ __global__ void maxpool_kernel(const PoolArgs a) {
     elem_t* eo = reinterpret_cast<elem_t*>(&o);
 #pragma unroll
     for (int i = 0; i < V; ++i) eo[i] = Elem<DT>::from_f32(best[i]);
-    const long long ooff = ((((n * a.To + to) * a.Ho + ho) * a.Wo + wo) * a.C + c) * sizeof(elem_t);
+    const long long ooff = ((((n * a.To + to) * a.Ho + ho) * a.Wo + wo) * a.out_ld + c) * sizeof(elem_t);
     *reinterpret_cast<uint4*>(a.out + ooff) = o;
 }
 
@@ -59,8 +60,8 @@ __global__ void maxpool_kernel(const PoolArgs a) {
 // 64 channels per workgroup; the 4 waves take interleaved window positions (independent loads in
 // flight), partial sums meet in LDS.
 template <int DT>
-__global__ __launch_bounds__(256) void avgpool_kernel(const char* __restrict__ in, float* __restrict__ pooled, int T,
-                                                      int H, int W, int C, int kt, int kh, int kw, int To, int Ho,
+__global__ __launch_bounds__(256) void avgpool_kernel(const char* __restrict__ in, float* __restrict__ pooled, int pooled_ld,
+                                                      int T, int H, int W, int C, int kt, int kh, int kw, int To, int Ho,
                                                       int Wo) {
     typedef typename Elem<DT>::type elem_t;
     __shared__ float part[4][64];
@@ -84,12 +85,12 @@ __global__ __launch_bounds__(256) void avgpool_kernel(const char* __restrict__ i
     part[ws][cl] = s;
     __syncthreads();
     if (ws == 0 && c < C)
-        pooled[(long long)blockIdx.y * C + c] = (part[0][cl] + part[1][cl] + part[2][cl] + part[3][cl]) / (float)win;
+        pooled[(long long)blockIdx.y * pooled_ld + c] = (part[0][cl] + part[1][cl] + part[2][cl] + part[3][cl]) / (float)win;
 }
 
 // nn.Linear on the pooled vector: logits[row][k] = dot(pooled[row], w[k]) + b[k]
 __global__ void fc_kernel(const float* __restrict__ pooled, const float* __restrict__ w, const float* __restrict__ b,
-                          int C, int num_classes, float* __restrict__ logits) {
+                          int C, int num_classes, float* __restrict__ logits) {   // pooled rows are C-contiguous
     __shared__ float red[4];
     const long long row = blockIdx.x;
     for (int k = 0; k < num_classes; ++k) {
@@ -136,6 +137,8 @@ extern "C" int af_maxpool3d(const af_pool_desc* d, const void* in, void* out, vo
     a.kt = d->kt; a.kh = d->kh; a.kw = d->kw; a.st = d->st; a.sh = d->sh; a.sw = d->sw;
     a.pt = d->pt; a.ph = d->ph; a.pw = d->pw; a.To = d->to; a.Ho = d->ho; a.Wo = d->wo;
     const int v = d->dtype == AF_F32 ? 4 : 8;
+    a.out_ld = d->out_ld ? d->out_ld : d->c;
+    AF_REQUIRE(a.out_ld >= d->c && a.out_ld % v == 0, "maxpool: bad out_ld %d", a.out_ld);
     a.total = (long long)d->n * d->to * d->ho * d->wo * (d->c / v);
     const long long blocks = (a.total + 255) / 256;
     AF_REQUIRE(blocks <= 0x7fffffffLL, "maxpool: grid too large");
@@ -148,25 +151,50 @@ extern "C" int af_maxpool3d(const af_pool_desc* d, const void* in, void* out, vo
     return AF_OK;
 }
 
+static int launch_avgpool(const af_pool_desc* d, const void* in, float* pooled, int pooled_ld, hipStream_t s) {
+    const long long rows = (long long)d->n * d->to * d->ho * d->wo;
+    AF_REQUIRE(rows <= 65535, "avgpool: too many output positions (%lld)", rows);
+    dim3 g((d->c + 63) / 64, (unsigned)rows), b(256);
+    if (d->dtype == AF_F32)
+        hipLaunchKernelGGL((avgpool_kernel<AF_F32>), g, b, 0, s, (const char*)in, pooled, pooled_ld, d->t, d->h, d->w, d->c, d->kt, d->kh, d->kw, d->to, d->ho, d->wo);
+    else if (d->dtype == AF_BF16)
+        hipLaunchKernelGGL((avgpool_kernel<AF_BF16>), g, b, 0, s, (const char*)in, pooled, pooled_ld, d->t, d->h, d->w, d->c, d->kt, d->kh, d->kw, d->to, d->ho, d->wo);
+    else
+        hipLaunchKernelGGL((avgpool_kernel<AF_F16>), g, b, 0, s, (const char*)in, pooled, pooled_ld, d->t, d->h, d->w, d->c, d->kt, d->kh, d->kw, d->to, d->ho, d->wo);
+    AF_CHECK_LAUNCH("avgpool_kernel");
+    return AF_OK;
+}
+
+static int check_avgpool(const af_pool_desc* d, const char* what) {
+    int rc = check_pool(d, what, false);
+    if (rc) return rc;
+    AF_REQUIRE(d->st == 1 && d->sh == 1 && d->sw == 1 && d->pt == 0 && d->ph == 0 && d->pw == 0,
+               "%s: AvgPool3d(kernel, stride=1, padding=0) only (head_helper.py:54)", what);
+    return AF_OK;
+}
+
+extern "C" int af_avgpool(const af_pool_desc* d, const void* in, float* pooled, int pooled_ld, void* stream) {
+    AF_REQUIRE(in && pooled, "avgpool: null argument");
+    int rc = check_avgpool(d, "avgpool");
+    if (rc) return rc;
+    AF_REQUIRE(pooled_ld >= d->c, "avgpool: pooled_ld %d < channels %d", pooled_ld, d->c);
+    return launch_avgpool(d, in, pooled, pooled_ld, (hipStream_t)stream);
+}
+
+extern "C" int af_linear(const float* x, const float* w, const float* b, int rows, int in_features, int out_features,
+                         float* y, void* stream) {
+    AF_REQUIRE(x && w && b && y && rows > 0 && in_features > 0 && out_features > 0, "linear: bad argument");
+    hipLaunchKernelGGL(fc_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, w, b, in_features, out_features, y);
+    AF_CHECK_LAUNCH("fc_kernel");
+    return AF_OK;
+}
+
 extern "C" int af_avgpool_fc(const af_pool_desc* d, const void* in, const float* fc_w, const float* fc_b,
                              int num_classes, float* pooled, float* logits, void* stream) {
     AF_REQUIRE(in && fc_w && fc_b && pooled && logits && num_classes > 0, "avgpool_fc: null argument");
-    int rc = check_pool(d, "avgpool_fc", false);
+    int rc = check_avgpool(d, "avgpool_fc");
     if (rc) return rc;
-    AF_REQUIRE(d->st == 1 && d->sh == 1 && d->sw == 1 && d->pt == 0 && d->ph == 0 && d->pw == 0,
-               "avgpool_fc: AvgPool3d(kernel, stride=1, padding=0) only (head_helper.py:54)");
-    const long long rows = (long long)d->n * d->to * d->ho * d->wo;
-    AF_REQUIRE(rows <= 65535, "avgpool_fc: too many output positions (%lld)", rows);
-    hipStream_t s = (hipStream_t)stream;
-    dim3 g((d->c + 63) / 64, (unsigned)rows), b(256);
-    if (d->dtype == AF_F32)
-        hipLaunchKernelGGL((avgpool_kernel<AF_F32>), g, b, 0, s, (const char*)in, pooled, d->t, d->h, d->w, d->c, d->kt, d->kh, d->kw, d->to, d->ho, d->wo);
-    else if (d->dtype == AF_BF16)
-        hipLaunchKernelGGL((avgpool_kernel<AF_BF16>), g, b, 0, s, (const char*)in, pooled, d->t, d->h, d->w, d->c, d->kt, d->kh, d->kw, d->to, d->ho, d->wo);
-    else
-        hipLaunchKernelGGL((avgpool_kernel<AF_F16>), g, b, 0, s, (const char*)in, pooled, d->t, d->h, d->w, d->c, d->kt, d->kh, d->kw, d->to, d->ho, d->wo);
-    AF_CHECK_LAUNCH("avgpool_kernel");
-    hipLaunchKernelGGL(fc_kernel, dim3((unsigned)rows), dim3(256), 0, s, pooled, fc_w, fc_b, d->c, num_classes, logits);
-    AF_CHECK_LAUNCH("fc_kernel");
-    return AF_OK;
+    rc = launch_avgpool(d, in, pooled, d->c, (hipStream_t)stream);
+    if (rc) return rc;
+    return af_linear(pooled, fc_w, fc_b, d->n * d->to * d->ho * d->wo, d->c, num_classes, logits, stream);
 }

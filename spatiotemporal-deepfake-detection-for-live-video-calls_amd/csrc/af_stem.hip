@@ -28,18 +28,20 @@ struct StemArgs {
     int Tp, Hp, Wp;      // padded dims
     int kt, kh;
     int To, Ho, Wo;
+    int cout;            // real output channels (<= 16 * TN; the weight image is padded to 16 * TN rows)
     long long M;
 };
 
 // NCH = 16-byte chunks per (dt,dh) K-row = 32 elements / EPC : fp32 8, 16-bit 4
-template <int DT>
+// TN = channel tiles of 16: 4 for the 64-channel stems, 1 for SlowFast's 8-channel Fast-pathway stem
+template <int DT, int TN>
 __global__ __launch_bounds__(256, 2) void stem_kernel(const StemArgs a) {
     typedef Elem<DT> E;
     constexpr int EPC = E::EPC;
     constexpr int ES = 16 / EPC;
     constexpr int NCH = 32 / EPC;
     constexpr int KK = NCH / 4;             // fragment reads per K-row (fp32 2, 16-bit 1)
-    constexpr int COUT = 64, TN = 4, TM = 4;
+    constexpr int COUT = 16 * TN, TM = 4;
     constexpr int PIXB = 4 * ES;            // bytes per padded pixel
 
     extern __shared__ uint4 wlds[];         // [kh][NCH][64]
@@ -102,27 +104,32 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const StemArgs a) {
 #pragma unroll
         for (int j = 0; j < TM; ++j) {
             const long long m = m0 + j * 16 + frow;
-            if (m < a.M) {
+            if (m < a.M && ch < a.cout) {
                 f32x4 v = acc[i][j] * sc + sf;
                 v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
-                Vec4<DT>::store(a.out + (m * COUT + ch) * ES, v);
+                Vec4<DT>::store(a.out + (m * a.cout + ch) * ES, v);
             }
         }
     }
 }
 
-template <int DT>
-static int launch_stem(const StemArgs& a, hipStream_t stream) {
+template <int DT, int TN>
+static int launch_stem_tn(const StemArgs& a, hipStream_t stream) {
     constexpr int NCH = 32 / Elem<DT>::EPC;
-    const int lds = a.kh * NCH * 64 * 16;
+    const int lds = a.kh * NCH * (16 * TN) * 16;
     const long long blocks = (a.M + 255) / 256;
     if (blocks > 0x7fffffffLL) return set_error(AF_ERR_ARG, "stem: grid too large");
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_kernel<DT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_kernel<DT, TN>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return set_error(AF_ERR_LAUNCH, "stem: hipFuncSetAttribute: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL((stem_kernel<DT>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((stem_kernel<DT, TN>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
     AF_CHECK_LAUNCH("stem_kernel");
     return AF_OK;
+}
+
+template <int DT>
+static int launch_stem(const StemArgs& a, hipStream_t stream) {
+    return a.cout <= 16 ? launch_stem_tn<DT, 1>(a, stream) : launch_stem_tn<DT, 4>(a, stream);
 }
 
 }  // namespace af
@@ -132,7 +139,8 @@ extern "C" int af_stem_conv_bn_relu(const af_conv_desc* d, const void* stem_in, 
     using namespace af;
     AF_REQUIRE(d && stem_in && w_packed && scale && shift && out, "stem: null argument");
     AF_REQUIRE(dtype_ok(d->dtype), "stem: bad dtype %d", d->dtype);
-    AF_REQUIRE(d->cin == 3 && d->cout == 64, "stem: expects 3 -> 64 channels (got %d -> %d)", d->cin, d->cout);
+    AF_REQUIRE(d->cin == 3 && (d->cout == 64 || (d->cout > 0 && d->cout <= 16 && d->cout % 4 == 0)),
+               "stem: expects 3 -> 64 (or <= 16) channels (got %d -> %d)", d->cin, d->cout);
     AF_REQUIRE(d->kh == 7 && d->kw == 7 && d->sh == 2 && d->sw == 2 && d->st == 1 && d->ph == 3 && d->pw == 3,
                "stem: expects a [kt,7,7] kernel, stride [1,2,2], pad [kt/2,3,3]");
     AF_REQUIRE(d->kt >= 1 && d->kt <= 2 * AF_STEM_PAD_T + 1 && (d->kt & 1) && d->pt == d->kt / 2, "stem: bad kt/pt");
@@ -144,7 +152,7 @@ extern "C" int af_stem_conv_bn_relu(const af_conv_desc* d, const void* stem_in, 
     StemArgs a;
     a.in = (const char*)stem_in; a.w = (const char*)w_packed; a.scale = scale; a.shift = shift; a.out = (char*)out;
     a.Tp = d->t + 2 * AF_STEM_PAD_T; a.Hp = d->h + 2 * AF_STEM_PAD_H; a.Wp = d->w + AF_STEM_PAD_W_TOTAL;
-    a.kt = d->kt; a.kh = d->kh; a.To = to; a.Ho = ho; a.Wo = wo;
+    a.kt = d->kt; a.kh = d->kh; a.To = to; a.Ho = ho; a.Wo = wo; a.cout = d->cout;
     a.M = (long long)d->n * to * ho * wo;
     // temporal halo is AF_STEM_PAD_T; a kernel with kt < 5 starts (PAD_T - pt) planes into it
     a.in += (long long)(AF_STEM_PAD_T - d->pt) * a.Hp * a.Wp * 4 * dtype_size(d->dtype);

@@ -1,10 +1,10 @@
-"""Host side of the HIP forward: turns a NetSpec + checkpoint tensors into a flat list of
+"""Host side of the HIP forward: turns a network spec + checkpoint tensors into a flat list of
 libafhip ops over caller-owned HBM buffers, and runs it with ONE C call per forward.
 
-What this orchestrates is the reference's ``ResNet.forward``
-(altfreezing/slowfast/models/video_model_builder.py:561-578): s1 -> s2 -> pathway0_pool ->
-s3 -> s4 -> s5 -> head, with every Conv3d+BatchNorm3d(+add)(+ReLU) group collapsed into one
-kernel launch.  PyTorch is used only to own device memory and the stream.
+What this orchestrates is the reference's ``ResNet.forward`` / ``SlowFast.forward``
+(altfreezing/slowfast/models/video_model_builder.py:561-578, :370-387): stem(s) -> [lateral] -> s2 -> [lateral] ->
+pool -> s3 -> ... -> head, with every Conv3d+BatchNorm3d(+add)(+ReLU)(+pool) group collapsed into one kernel
+launch.  PyTorch is used only to own device memory and the stream.
 """
 import ctypes as C
 from typing import Dict, List, Optional
@@ -12,8 +12,8 @@ from typing import Dict, List, Optional
 import torch
 
 from . import _lib
-from ._lib import ConvDesc, Op, PoolDesc, check, lib
-from .arch import BN_EPS, ConvSpec, NetSpec, PoolSpec
+from ._lib import Op, check, lib
+from .arch import BN_EPS, ConvSpec, NetSpec, PoolSpec, SlowFastSpec
 
 _TORCH_DTYPE = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}
 
@@ -44,15 +44,29 @@ def _stream_ptr(device):
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
+def _pool_out(dims, p: PoolSpec):
+    return tuple((d + 2 * pp - k) // s + 1 for d, k, s, pp in zip(dims, p.kernel, p.stride, p.pad))
+
+
+def _is_pool(p: PoolSpec, k, s, pad):
+    return (tuple(p.kernel), tuple(p.stride), tuple(p.pad)) == (k, s, pad)
+
+
+def _stages_of(spec):
+    if isinstance(spec, SlowFastSpec):
+        return [st for pair in spec.stages for st in pair]
+    return list(spec.stages)
+
 class PackedWeights:
     """Device-resident, kernel-ready copy of a checkpoint: per conv a packed weight in the compute
     dtype plus fp32 BatchNorm scale/shift; fp32 head.  Built with HIP kernels (af_pack.hip)."""
 
-    def __init__(self, spec: NetSpec, state: Dict[str, torch.Tensor], dtype: str, device):
+    def __init__(self, spec, state: Dict[str, torch.Tensor], dtype: str, device):
         self.dtype = dtype
         code = _lib.DTYPE_CODES[dtype]
         es = 4 if dtype == "f32" else 2
         st = _stream_ptr(device)
+        stems = set(c.conv for c in (spec.stems if isinstance(spec, SlowFastSpec) else (spec.stem,)))
         self.w, self.scale, self.shift = {}, {}, {}
         for cv in spec.convs():
             w = state[cv.conv + ".weight"].detach().to(device=device, dtype=torch.float32).contiguous()
@@ -65,7 +79,7 @@ class PackedWeights:
             check(lib.af_fold_bn(_ptr(bn[0]), _ptr(bn[1]), _ptr(bn[2]), _ptr(bn[3]), BN_EPS, cv.cout,
                                  _ptr(scale), _ptr(shift), st), "af_fold_bn")
             kt, kh, kw = cv.kernel
-            if cv is spec.stem:
+            if cv.conv in stems:
                 nbytes = lib.af_packed_stem_weight_bytes(cv.cout, kt, kh, code)
                 packed = torch.empty(nbytes // es, dtype=_TORCH_DTYPE[dtype], device=device)
                 check(lib.af_pack_stem_weight(_ptr(w), cv.cout, kt, kh, kw, code, _ptr(packed), st),
@@ -79,7 +93,7 @@ class PackedWeights:
         # block 0 of every stage: last 1x1x1 + projection shortcut share one accumulator (af_conv3d_dual_bn_act):
         # both weights get their BN scale folded in (fp32, before the rounding), shifts are summed
         self.w_folded, self.shift_sum, self.ones = {}, {}, {}
-        for stage in spec.stages:
+        for stage in _stages_of(spec):
             for blk in stage.blocks:
                 if blk.branch1 is None:
                     continue
@@ -98,180 +112,293 @@ class PackedWeights:
         torch.cuda.current_stream(device).synchronize()      # sources may be freed by the caller
 
 
+class _Plan:
+    """Accumulates plan entries (dicts) and the element count every named activation buffer must hold."""
+
+    def __init__(self, batch):
+        self.batch, self.entries, self.sizes = batch, [], {}
+
+    def need(self, buf, dims, width):
+        self.sizes[buf] = max(self.sizes.get(buf, 0), self.batch * dims[0] * dims[1] * dims[2] * width)
+
+    def add(self, **e):
+        self.entries.append(e)
+
+    def stage(self, stage, d, cur, nxt, a_buf, b_buf, last_ld=None, tpool_last=False):
+        """One pathway's ResStage.  ``last_ld``: row stride of the stage's final output (room for the lateral's
+        channels).  Returns (dims, channels, buffer holding the output, the other trunk buffer)."""
+        c = None
+        nblk = len(stage.blocks)
+        for bi, blk in enumerate(stage.blocks):
+            last = bi == nblk - 1
+            da = blk.a.out_dims(*d)
+            self.add(kind="conv", cv=blk.a, din=d, dout=da, src=cur, dst=a_buf); self.need(a_buf, da, blk.a.cout)
+            db = blk.b.out_dims(*da)
+            self.add(kind="conv", cv=blk.b, din=da, dout=db, src=a_buf, dst=b_buf); self.need(b_buf, db, blk.b.cout)
+            dc = blk.c.out_dims(*db)
+            ld = last_ld if (last and last_ld) else blk.c.cout
+            # the temporal max-pool after s2 rides in the epilogue of s2's last conv when it can
+            tp = tpool_last and last and blk.branch1 is None and dc[0] % 2 == 0
+            dstore = (dc[0] // 2,) + tuple(dc[1:]) if tp else dc
+            if blk.branch1 is not None:      # c conv + projection shortcut in one launch; no shortcut tensor
+                assert blk.branch1.out_dims(*d) == dc
+                self.add(kind="dual", cv=blk.c, cv2=blk.branch1, din=db, din2=d, dout=dc, src=b_buf, src2=cur, dst=nxt, ld=ld)
+            else:
+                self.add(kind="conv", cv=blk.c, din=db, dout=dc, src=b_buf, dst=nxt, res=cur, ld=ld, tpool=tp)
+            self.need(nxt, dstore, ld)
+            cur, nxt = nxt, cur
+            d, c = dstore, blk.c.cout
+        return d, c, cur, nxt
+
+
 class Engine:
     """Op list + activation buffers for one (batch, dtype).  ``run_*`` enqueue the whole forward on
     the current torch stream and return the engine-owned logits / pooled-feature tensors."""
 
-    def __init__(self, spec: NetSpec, weights: PackedWeights, batch: int, device, dims=None):
+    def __init__(self, spec, weights: PackedWeights, batch: int, device, dims=None):
         self.spec, self.weights, self.batch, self.device = spec, weights, batch, device
         self.dtype = weights.dtype
         self.code = _lib.DTYPE_CODES[self.dtype]
-        tdt = _TORCH_DTYPE[self.dtype]
         T, H, W = dims or (spec.num_frames, spec.crop, spec.crop)
         self.in_dims = (T, H, W)
-        es = 4 if self.dtype == "f32" else 2
+        plan = _Plan(batch)
+        if isinstance(spec, SlowFastSpec):
+            self._plan_slowfast(plan, spec, T, H, W)
+        else:
+            self._plan_i3d(plan, spec, T, H, W)
+        self._materialise(plan)
 
-        # ---- walk the network once to size the buffers --------------------------------------
-        plan = []           # (kind, spec, in_dims, out_dims, in_buf, out_buf, res_buf)
-        sizes = {"P0": 0, "P1": 0, "A": 0, "B": 0}
-
-        def need(buf, dims, c):
-            sizes[buf] = max(sizes[buf], batch * dims[0] * dims[1] * dims[2] * c)
-
-        def pool_out(dims, p: PoolSpec):
-            return tuple((d + 2 * pp - k) // s + 1 for d, k, s, pp in zip(dims, p.kernel, p.stride, p.pad))
-
+    # -- plans -----------------------------------------------------------------------------------------
+    def _plan_i3d(self, plan: _Plan, spec: NetSpec, T, H, W):
+        self.inputs = [("IN", (T, H, W), 1)]                       # (stem-input buffer, dims, temporal stride)
         cur, nxt = "P0", "P1"
         d = spec.stem.out_dims(T, H, W)
-        d2 = pool_out(d, spec.stem_pool)
-        sp_ = spec.stem_pool
+        d2 = _pool_out(d, spec.stem_pool)
         fuse_stem_pool = (self.dtype != "f32" and d[2] <= 128 and spec.stem.cout == 64 and
-                          (tuple(sp_.kernel), tuple(sp_.stride), tuple(sp_.pad)) == ((1, 3, 3), (1, 2, 2), (0, 1, 1)))
+                          _is_pool(spec.stem_pool, (1, 3, 3), (1, 2, 2), (0, 1, 1)))
         if fuse_stem_pool:        # conv + BN + ReLU + max-pool in one launch; the conv output never reaches HBM
-            plan.append(("stem_pool", spec.stem, (T, H, W), d, "IN", cur, None)); need(cur, d2, spec.stem.cout)
+            plan.add(kind="stem_pool", cv=spec.stem, din=(T, H, W), dout=d, src="IN", dst=cur); plan.need(cur, d2, spec.stem.cout)
         else:
-            plan.append(("stem", spec.stem, (T, H, W), d, "IN", cur, None)); need(cur, d, spec.stem.cout)
-            plan.append(("pool", (spec.stem_pool, spec.stem.cout), d, d2, cur, nxt, None)); need(nxt, d2, spec.stem.cout)
+            plan.add(kind="stem", cv=spec.stem, din=(T, H, W), dout=d, src="IN", dst=cur); plan.need(cur, d, spec.stem.cout)
+            plan.add(kind="pool", pool=spec.stem_pool, ch=spec.stem.cout, din=d, dout=d2, src=cur, dst=nxt)
+            plan.need(nxt, d2, spec.stem.cout)
             cur, nxt = nxt, cur
-        d, c = d2, spec.stem.cout
-        p2 = spec.pool_after_s2
-        fuse_tpool = (tuple(p2.kernel), tuple(p2.stride), tuple(p2.pad)) == ((2, 1, 1), (2, 1, 1), (0, 0, 0))
+        d = d2
+        fuse_tpool = _is_pool(spec.pool_after_s2, (2, 1, 1), (2, 1, 1), (0, 0, 0))
+        c = spec.stem.cout
         for si, stage in enumerate(spec.stages):
-            for bi, blk in enumerate(stage.blocks):
-                res = cur
-                da = blk.a.out_dims(*d)
-                plan.append(("conv", blk.a, d, da, cur, "A", None)); need("A", da, blk.a.cout)
-                db = blk.b.out_dims(*da)
-                plan.append(("conv", blk.b, da, db, "A", "B", None)); need("B", db, blk.b.cout)
-                dc = blk.c.out_dims(*db)
-                # the temporal max-pool after s2 rides in the epilogue of s2's last conv when it can
-                tp = fuse_tpool and si == 0 and bi == len(stage.blocks) - 1 and blk.branch1 is None and dc[0] % 2 == 0
-                dstore = (dc[0] // 2,) + tuple(dc[1:]) if tp else dc
-                if blk.branch1 is not None:      # c conv + projection shortcut in one launch; no shortcut tensor
-                    assert blk.branch1.out_dims(*d) == dc
-                    plan.append(("dual", (blk.c, blk.branch1, d), db, dc, "B", nxt, cur)); need(nxt, dc, blk.c.cout)
-                else:
-                    plan.append(("conv_tpool" if tp else "conv", blk.c, db, dc, "B", nxt, res)); need(nxt, dstore, blk.c.cout)
-                cur, nxt = nxt, cur
-                d, c = dstore, blk.c.cout
-            if si == 0 and not tp:
-                d2 = pool_out(d, spec.pool_after_s2)
-                plan.append(("pool", (spec.pool_after_s2, c), d, d2, cur, nxt, None)); need(nxt, d2, c)
+            d, c, cur, nxt = plan.stage(stage, d, cur, nxt, "A", "B", tpool_last=(fuse_tpool and si == 0))
+            if si == 0 and not plan.entries[-1].get("tpool"):
+                # pathway0_pool as its own launch (odd frame counts / other pool shapes)
+                d2 = _pool_out(d, spec.pool_after_s2)
+                plan.add(kind="pool", pool=spec.pool_after_s2, ch=c, din=d, dout=d2, src=cur, dst=nxt); plan.need(nxt, d2, c)
                 cur, nxt = nxt, cur
                 d = d2
         hp = tuple(spec.head_pool)
         dh = tuple(di - k + 1 for di, k in zip(d, hp))
         if min(dh) < 1:
             raise ValueError("input %s too small for the head pool %s" % ((T, H, W), hp))
-        plan.append(("head", (hp, c), d, dh, cur, "LOGITS", None))
-        self.head_positions = dh[0] * dh[1] * dh[2]
-        self.head_dims = dh
+        self.head_dims, self.head_width = dh, c
+        plan.add(kind="head", pool=hp, ch=c, din=d, dout=dh, src=cur)
 
-        # ---- buffers (caller-owned HBM, allocated once) ------------------------------------------
-        stem_in_bytes = lib.af_stem_input_bytes(batch, T, H, W, self.code)
-        self.buf = {k: torch.empty(max(v, 8), dtype=tdt, device=device) for k, v in sizes.items()}
-        self.buf["IN"] = torch.zeros(stem_in_bytes // es, dtype=tdt, device=device)   # halos stay zero forever
-        self.pooled = torch.empty((batch, self.head_positions, c), dtype=torch.float32, device=device)
+    def _plan_slowfast(self, plan: _Plan, spec: SlowFastSpec, T, H, W):
+        if T % spec.alpha:
+            raise ValueError("SlowFast needs a frame count divisible by alpha=%d (got %d)" % (spec.alpha, T))
+        Ts = T // spec.alpha
+        self.inputs = [("IN_S", (Ts, H, W), spec.alpha), ("IN_F", (T, H, W), 1)]
+        fuse_w = [f.cout for f in spec.fuses]                         # channels each lateral adds to the Slow tensor
+        # stems (+ max-pool); the Slow pool writes at the widened row stride so the lateral can append its channels
+        ds = spec.stems[0].out_dims(Ts, H, W); ds2 = _pool_out(ds, spec.stem_pool)
+        df = spec.stems[1].out_dims(T, H, W); df2 = _pool_out(df, spec.stem_pool)
+        ld0 = spec.stems[0].cout + fuse_w[0]
+        plan.add(kind="stem", cv=spec.stems[0], din=(Ts, H, W), dout=ds, src="IN_S", dst="S1"); plan.need("S1", ds, spec.stems[0].cout)
+        plan.add(kind="pool", pool=spec.stem_pool, ch=spec.stems[0].cout, din=ds, dout=ds2, src="S1", dst="S0", ld=ld0)
+        plan.need("S0", ds2, ld0)
+        plan.add(kind="stem", cv=spec.stems[1], din=(T, H, W), dout=df, src="IN_F", dst="F1"); plan.need("F1", df, spec.stems[1].cout)
+        plan.add(kind="pool", pool=spec.stem_pool, ch=spec.stems[1].cout, din=df, dout=df2, src="F1", dst="F0")
+        plan.need("F0", df2, spec.stems[1].cout)
+        scur, snxt, fcur, fnxt = "S0", "S1", "F0", "F1"
+        ds, df, cs = ds2, df2, spec.stems[0].cout
+
+        def lateral(fz: ConvSpec, dfast, fbuf, sbuf, c_slow, ld):
+            do = fz.out_dims(*dfast)                                   # FuseFastToSlow: conv + BN + ReLU into the Slow rows
+            plan.add(kind="conv", cv=fz, din=dfast, dout=do, src=fbuf, dst=sbuf, ld=ld, ch_off=c_slow)
+            return do
+
+        if lateral(spec.fuses[0], df, fcur, scur, cs, ld0) != ds:
+            raise ValueError("the Fast->Slow lateral does not land on the Slow grid")
+        cf = spec.stems[1].cout
+        for si, (slow, fast) in enumerate(spec.stages):
+            has_fuse = si + 1 < len(spec.fuses)
+            ld = slow.blocks[-1].c.cout + (fuse_w[si + 1] if has_fuse else 0)
+            ds, cs, scur, snxt = plan.stage(slow, ds, scur, snxt, "A_S", "B_S", last_ld=ld)
+            df, cf, fcur, fnxt = plan.stage(fast, df, fcur, fnxt, "A_F", "B_F")
+            if has_fuse and lateral(spec.fuses[si + 1], df, fcur, scur, cs, ld) != ds:
+                raise ValueError("the Fast->Slow lateral does not land on the Slow grid")
+        hs, hf = (tuple(p) for p in spec.head_pools)
+        dhs = tuple(di - k + 1 for di, k in zip(ds, hs))
+        dhf = tuple(di - k + 1 for di, k in zip(df, hf))
+        if min(dhs) < 1 or dhs != dhf:
+            raise ValueError("input %s does not fit the SlowFast head pools %s / %s" % ((T, H, W), hs, hf))
+        self.head_dims, self.head_width = dhs, cs + cf
+        plan.add(kind="avgpool", pool=hs, ch=cs, din=ds, dout=dhs, src=scur, ch_off=0)
+        plan.add(kind="avgpool", pool=hf, ch=cf, din=df, dout=dhf, src=fcur, ch_off=cs)
+        plan.add(kind="linear")
+
+    # -- buffers + op list ------------------------------------------------------------------------------
+    def _materialise(self, plan: _Plan):
+        batch, device, weights, spec = self.batch, self.device, self.weights, self.spec
+        tdt = _TORCH_DTYPE[self.dtype]
+        es = 4 if self.dtype == "f32" else 2
+        self.buf = {k: torch.empty(max(v, 8), dtype=tdt, device=device) for k, v in plan.sizes.items()}
+        for name, dims, _ in self.inputs:                           # padded stem inputs: halos stay zero forever
+            nbytes = lib.af_stem_input_bytes(batch, dims[0], dims[1], dims[2], self.code)
+            self.buf[name] = torch.zeros(nbytes // es, dtype=tdt, device=device)
+        self.head_positions = self.head_dims[0] * self.head_dims[1] * self.head_dims[2]
+        self.pooled = torch.empty((batch, self.head_positions, self.head_width), dtype=torch.float32, device=device)
         self.logits = torch.empty((batch, self.head_positions * spec.num_classes), dtype=torch.float32, device=device)
-        self.buf["LOGITS"] = self.logits
 
-        # ---- op list ----------------------------------------------------------------------------------
-        n_ops = len(plan) + 1
-        self.ops = (Op * n_ops)()
-        self.op_names: List[str] = ["input_pack"]
-        self.op_macs: List[int] = [0]
-        pk = self.ops[0]
-        pk.kind = _lib.AF_OP_PACK_F32
-        pk.tag = TAG_PACK
-        pk.conv.n, pk.conv.t, pk.conv.h, pk.conv.w, pk.conv.dtype = batch, T, H, W, self.code
-        pk.out = self.buf["IN"].data_ptr()
-        for i, (kind, sp, din, dout, bi, bo, br) in enumerate(plan, start=1):
-            op = self.ops[i]
-            op.in_ = self.buf[bi].data_ptr()
-            op.out = self.buf[bo].data_ptr()
-            if kind in ("stem", "stem_pool", "conv", "conv_tpool"):
-                cv: ConvSpec = sp
+        n_pack = len(self.inputs)
+        self.n_ops = n_pack + len(plan.entries)
+        self.ops = (Op * self.n_ops)()
+        self.op_names: List[str] = []
+        self.op_macs: List[int] = []
+        self.op_dst: List[Optional[str]] = [name for name, _, _ in self.inputs] + [e.get("dst") for e in plan.entries]
+        for i, (name, dims, _) in enumerate(self.inputs):
+            pk = self.ops[i]
+            pk.kind, pk.tag = _lib.AF_OP_PACK_F32, TAG_PACK
+            pk.conv.n, (pk.conv.t, pk.conv.h, pk.conv.w), pk.conv.dtype = batch, dims, self.code
+            pk.out = self.buf[name].data_ptr()
+            self.op_names.append("input_pack" if n_pack == 1 else "input_pack_" + name)
+            self.op_macs.append(0)
+
+        def fill_conv(cd, cv: ConvSpec, din, dout, relu):
+            cd.n, (cd.t, cd.h, cd.w), cd.cin, cd.cout = batch, din, cv.cin, cv.cout
+            cd.kt, cd.kh, cd.kw = cv.kernel
+            cd.st, cd.sh, cd.sw = cv.stride
+            cd.pt, cd.ph, cd.pw = cv.pad
+            cd.to, cd.ho, cd.wo = dout
+            cd.relu, cd.dtype = int(relu), self.code
+
+        def fill_pool(pd, din, ch, kernel, stride, pad, dout):
+            pd.n, (pd.t, pd.h, pd.w), pd.c = batch, din, ch
+            pd.kt, pd.kh, pd.kw = kernel
+            pd.st, pd.sh, pd.sw = stride
+            pd.pt, pd.ph, pd.pw = pad
+            pd.to, pd.ho, pd.wo = dout
+            pd.dtype = self.code
+
+        for k, e in enumerate(plan.entries):
+            op = self.ops[n_pack + k]
+            kind = e["kind"]
+            if "src" in e:
+                op.in_ = self.buf[e["src"]].data_ptr()
+            if "dst" in e:
+                op.out = self.buf[e["dst"]].data_ptr() + e.get("ch_off", 0) * es
+            if kind in ("stem", "stem_pool", "conv"):
+                cv: ConvSpec = e["cv"]
                 op.kind = {"stem": _lib.AF_OP_STEM, "stem_pool": _lib.AF_OP_STEM_POOL}.get(kind, _lib.AF_OP_CONV)
-                op.conv.tpool = 1 if kind == "conv_tpool" else 0
-                op.tag = TAG_STEM if kind in ("stem", "stem_pool") else _conv_tag(cv)
-                cd = op.conv
-                cd.n, (cd.t, cd.h, cd.w), cd.cin, cd.cout = batch, din, cv.cin, cv.cout
-                cd.kt, cd.kh, cd.kw = cv.kernel
-                cd.st, cd.sh, cd.sw = cv.stride
-                cd.pt, cd.ph, cd.pw = cv.pad
-                cd.to, cd.ho, cd.wo = dout
-                # a, b and the stem carry their own ReLU; c (final_bn) takes the block's add + ReLU;
-                # the projection shortcut has neither (resnet_helper.py:311-326, 438-444)
-                cd.relu = 1 if (cv.relu or cv.final_bn) else 0
-                cd.dtype = self.code
+                op.tag = TAG_STEM if kind != "conv" else _conv_tag(cv)
+                # a, b, stems and laterals carry their own ReLU; c (final_bn) takes the block's add + ReLU; the
+                # projection shortcut has neither (resnet_helper.py:311-326, 438-444; video_model_builder.py:136-143)
+                fill_conv(op.conv, cv, e["din"], e["dout"], cv.relu or cv.final_bn)
+                op.conv.tpool = 1 if e.get("tpool") else 0
                 op.weight = weights.w[cv.conv].data_ptr()
                 op.scale = weights.scale[cv.conv].data_ptr()
                 op.shift = weights.shift[cv.conv].data_ptr()
-                op.residual = self.buf[br].data_ptr() if br is not None else None
-                op.out_ld = cv.cout
+                op.residual = self.buf[e["res"]].data_ptr() if e.get("res") else None
+                op.out_ld = e.get("ld", cv.cout)
                 self.op_names.append(cv.conv)
-                self.op_macs.append(batch * cv.macs(*din))
+                self.op_macs.append(batch * cv.macs(*e["din"]))
             elif kind == "dual":
-                cvc, cv1, din1 = sp
+                cvc, cv1 = e["cv"], e["cv2"]
                 op.kind, op.tag = _lib.AF_OP_CONV_DUAL, _conv_tag(cvc)
-                for cd, cv, dd in ((op.conv, cvc, din), (op.conv2, cv1, din1)):
-                    cd.n, (cd.t, cd.h, cd.w), cd.cin, cd.cout = batch, dd, cv.cin, cv.cout
-                    cd.kt, cd.kh, cd.kw = cv.kernel
-                    cd.st, cd.sh, cd.sw = cv.stride
-                    cd.pt, cd.ph, cd.pw = cv.pad
-                    cd.to, cd.ho, cd.wo = dout
-                    cd.relu, cd.dtype = 1, self.code
+                fill_conv(op.conv, cvc, e["din"], e["dout"], True)
+                fill_conv(op.conv2, cv1, e["din2"], e["dout"], True)
                 op.weight = weights.w_folded[cvc.conv].data_ptr()
                 op.weight2 = weights.w_folded[cv1.conv].data_ptr()
-                op.in2 = self.buf[br].data_ptr()
+                op.in2 = self.buf[e["src2"]].data_ptr()
                 op.scale = weights.ones[cvc.conv].data_ptr()
                 op.shift = weights.shift_sum[cvc.conv].data_ptr()
                 op.residual = None
-                op.out_ld = cvc.cout
+                op.out_ld = e.get("ld", cvc.cout)
                 self.op_names.append(cvc.conv + "+branch1")
-                self.op_macs.append(batch * (cvc.macs(*din) + cv1.macs(*din1)))
+                self.op_macs.append(batch * (cvc.macs(*e["din"]) + cv1.macs(*e["din2"])))
             elif kind == "pool":
-                p, ch = sp
+                p = e["pool"]
                 op.kind, op.tag = _lib.AF_OP_MAXPOOL, TAG_POOL
-                pd = op.pool
-                pd.n, (pd.t, pd.h, pd.w), pd.c = batch, din, ch
-                pd.kt, pd.kh, pd.kw = p.kernel
-                pd.st, pd.sh, pd.sw = p.stride
-                pd.pt, pd.ph, pd.pw = p.pad
-                pd.to, pd.ho, pd.wo = dout
-                pd.dtype = self.code
+                fill_pool(op.pool, e["din"], e["ch"], p.kernel, p.stride, p.pad, e["dout"])
+                op.pool.out_ld = e.get("ld", 0)
                 self.op_names.append("maxpool_%dx%dx%d" % tuple(p.kernel))
                 self.op_macs.append(0)
-            else:
-                hp_, ch = sp
+            elif kind == "head":
                 op.kind, op.tag = _lib.AF_OP_HEAD, TAG_HEAD
-                pd = op.pool
-                pd.n, (pd.t, pd.h, pd.w), pd.c = batch, din, ch
-                pd.kt, pd.kh, pd.kw = hp_
-                pd.st = pd.sh = pd.sw = 1
-                pd.pt = pd.ph = pd.pw = 0
-                pd.to, pd.ho, pd.wo = dout
-                pd.dtype = self.code
+                fill_pool(op.pool, e["din"], e["ch"], e["pool"], (1, 1, 1), (0, 0, 0), e["dout"])
                 op.weight = weights.fc_w.data_ptr()
                 op.scale = weights.fc_b.data_ptr()
                 op.aux = self.pooled.data_ptr()
+                op.out = self.logits.data_ptr()
                 op.num_classes = spec.num_classes
                 self.op_names.append("head")
                 self.op_macs.append(0)
-        self.n_ops = n_ops
+            elif kind == "avgpool":
+                op.kind, op.tag = _lib.AF_OP_AVGPOOL, TAG_HEAD
+                fill_pool(op.pool, e["din"], e["ch"], e["pool"], (1, 1, 1), (0, 0, 0), e["dout"])
+                op.out = self.pooled.data_ptr() + e["ch_off"] * 4
+                op.out_ld = self.head_width
+                self.op_names.append("head_avgpool_%d" % e["ch_off"])
+                self.op_macs.append(0)
+            elif kind == "linear":
+                op.kind, op.tag = _lib.AF_OP_LINEAR, TAG_HEAD
+                op.in_ = self.pooled.data_ptr()
+                op.weight = weights.fc_w.data_ptr()
+                op.scale = weights.fc_b.data_ptr()
+                op.pool.n, op.pool.c = batch * self.head_positions, self.head_width
+                op.num_classes = spec.num_classes
+                op.out = self.logits.data_ptr()
+                self.op_names.append("head_linear")
+                self.op_macs.append(0)
+            else:
+                raise KeyError(kind)
 
     # -- input binding -------------------------------------------------------------------------------------
-    def _bind_f32(self, x: torch.Tensor):
+    def _bind_f32(self, i: int, x: torch.Tensor, tstride: int = 1):
+        """Binds network input i to x.  ``tstride`` > 1 takes every tstride-th frame of x (the Slow pathway of a
+        single-clip SlowFast call): only the element stride handed to the pack kernel changes, nothing is copied."""
+        name, dims, _ = self.inputs[i]
         B, Cc, T, H, W = x.shape
-        if (B, Cc, T, H, W) != (self.batch, 3) + self.in_dims:
-            raise ValueError("expected input (%d,3,%d,%d,%d), got %s" % ((self.batch,) + self.in_dims + (tuple(x.shape),)))
-        pk = self.ops[0]
+        if (B, Cc, H, W) != (self.batch, 3, dims[1], dims[2]) or T != dims[0] * tstride:
+            raise ValueError("expected input (%d,3,%d,%d,%d), got %s"
+                             % (self.batch, dims[0] * tstride, dims[1], dims[2], tuple(x.shape)))
+        if x.dtype != torch.float32 or not x.is_cuda:
+            raise ValueError("inputs must be fp32 HIP tensors")
+        pk = self.ops[i]
         pk.kind = _lib.AF_OP_PACK_F32
         pk.in_ = x.data_ptr()
-        for i, s in enumerate(x.stride()):
-            pk.in_strides[i] = s
+        st = list(x.stride())
+        st[2] *= tstride
+        for k, s in enumerate(st):
+            pk.in_strides[k] = s
 
-    def _bind_u8(self, clips: torch.Tensor, mean, std):
+    def run_f32(self, *xs: torch.Tensor):
+        """One (B,3,T,H,W) fp32 device tensor per network input, any strides (the callers' normalised clip; SlowFast:
+        slow, fast).  A single tensor given to a two-input network is split by frame striding."""
+        if len(xs) == 1 and len(self.inputs) > 1:
+            for i, (_, _, ts) in enumerate(self.inputs):
+                self._bind_f32(i, xs[0], ts)
+        else:
+            if len(xs) != len(self.inputs):
+                raise ValueError("network takes %d inputs, got %d" % (len(self.inputs), len(xs)))
+            for i, x in enumerate(xs):
+                self._bind_f32(i, x)
+        check(lib.af_run_ops(self.ops, self.n_ops, _stream_ptr(self.device)), "af_run_ops")
+        return self.logits, self.pooled
+
+    def run_u8(self, clips: torch.Tensor, mean, std):
+        """clips: (B,T,H,W,3) uint8 device tensor in caller layout; normalisation fused into the prologue."""
+        assert clips.dtype == torch.uint8 and clips.is_cuda
+        if len(self.inputs) != 1:
+            raise ValueError("the uint8 prologue is wired for single-input networks")
         B, T, H, W, Cc = clips.shape
         if (B, T, H, W, Cc) != (self.batch,) + self.in_dims + (3,) or not clips.is_contiguous():
             raise ValueError("expected contiguous uint8 clips (%d,%d,%d,%d,3)" % ((self.batch,) + self.in_dims))
@@ -280,18 +407,6 @@ class Engine:
         pk.in_ = clips.data_ptr()
         for i in range(3):
             pk.mean[i], pk.std_[i] = float(mean[i]), float(std[i])
-
-    def run_f32(self, x: torch.Tensor):
-        """x: (B,3,T,H,W) fp32 device tensor, any strides (the callers' normalised clip)."""
-        assert x.dtype == torch.float32 and x.is_cuda
-        self._bind_f32(x)
-        check(lib.af_run_ops(self.ops, self.n_ops, _stream_ptr(self.device)), "af_run_ops")
-        return self.logits, self.pooled
-
-    def run_u8(self, clips: torch.Tensor, mean, std):
-        """clips: (B,T,H,W,3) uint8 device tensor in caller layout; normalisation fused into the prologue."""
-        assert clips.dtype == torch.uint8 and clips.is_cuda
-        self._bind_u8(clips, mean, std)
         check(lib.af_run_ops(self.ops, self.n_ops, _stream_ptr(self.device)), "af_run_ops")
         return self.logits, self.pooled
 
@@ -309,20 +424,19 @@ class Engine:
         return [float(v) for v in ms]
 
     def activation(self, op_index: int) -> torch.Tensor:
-        """Output of op ``op_index`` as an (N,T,H,W,C) view of its buffer (valid until overwritten)."""
+        """Output of op ``op_index`` as an (N,T,H,W,C) view of its buffer (valid until overwritten; ops that write
+        into a wider, concatenated row return the full-width rows)."""
         op = self.ops[op_index]
         if op.kind == _lib.AF_OP_STEM_POOL:
             shape = (op.conv.n, op.conv.to, (op.conv.ho - 1) // 2 + 1, (op.conv.wo - 1) // 2 + 1, op.conv.cout)
         elif op.kind in (_lib.AF_OP_STEM, _lib.AF_OP_CONV, _lib.AF_OP_CONV_DUAL):
-            shape = (op.conv.n, op.conv.to // 2 if op.conv.tpool else op.conv.to, op.conv.ho, op.conv.wo, op.conv.cout)
+            ld = op.out_ld or op.conv.cout
+            shape = (op.conv.n, op.conv.to // 2 if op.conv.tpool else op.conv.to, op.conv.ho, op.conv.wo, ld)
         elif op.kind == _lib.AF_OP_MAXPOOL:
-            shape = (op.pool.n, op.pool.to, op.pool.ho, op.pool.wo, op.pool.c)
+            shape = (op.pool.n, op.pool.to, op.pool.ho, op.pool.wo, op.pool.out_ld or op.pool.c)
         else:
             raise ValueError("op %d has no NDHWC output" % op_index)
         numel = 1
         for s in shape:
             numel *= s
-        for t in self.buf.values():
-            if t.data_ptr() == op.out:
-                return t[:numel].view(shape)
-        raise KeyError(op_index)
+        return self.buf[self.op_dst[op_index]][:numel].view(shape)      # rows from channel 0 of the destination buffer

@@ -1,0 +1,91 @@
+"""GPU: the two-pathway SlowFast-R50 on the HIP kernels against the golden
+logits and stage samples produced by the reference's own ``SlowFast`` module (tests/golden/f5_slowfast*).
+Tolerances as for the single-pathway net: f32 2e-4 (north star 1e-3), f16 1e-2, bf16 6e-2."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_json, load_npz
+from af_mi355x import arch, synth
+from af_mi355x.classifier import SlowFast8x8
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sf_weights():
+    g = load_json("f5_slowfast.json")
+    sd = synth.synthetic_state_dict(arch.slowfast_r50_spec(), seed=g["weights_seed"])
+    assert synth.state_dict_sha256(sd) == g["weights_sha256"]
+    return g, sd
+
+
+def _clip(c):
+    u8 = synth.synthetic_clips_u8(c["index"] + 1, seed=c["seed"], kind=c["kind"])[c["index"]:c["index"] + 1]
+    assert synth.tensor_sha256(u8) == c["clip_sha256"]
+    return synth.normalize_like_callers(u8).cuda()
+
+
+@pytest.mark.parametrize("dtype,tol", [("f32", 2e-4), ("f16", 1e-2), ("bf16", 6e-2)])
+def test_slowfast_logits_match_reference(sf_weights, dtype, tol):
+    g, sd = sf_weights
+    net = SlowFast8x8(precision=dtype)
+    net.load_state_dict(sd)
+    net = net.cuda().eval()
+    for c in g["clips"]:
+        x = _clip(c)
+        with torch.inference_mode():
+            y_list = net([x[:, :, ::g["alpha"]], x])["final_output"]      # the reference contract: [slow, fast]
+            y_one = net(x)["final_output"]                                  # one clip: Slow pathway = frame stride alpha
+        assert y_list.shape == (1, 1) and torch.equal(y_list, y_one)
+        err = abs(float(y_list[0, 0]) - c["logit_f32"])
+        print("slowfast %s %s: hip %.6f ref %.6f |d| %.2e" % (dtype, c["kind"], float(y_list[0, 0]), c["logit_f32"], err))
+        assert err <= tol
+
+
+def test_slowfast_stage_activations_f32(sf_weights):
+    g, sd = sf_weights
+    st = load_npz("f5_slowfast_stages.npz")
+    net = SlowFast8x8(precision="f32")
+    net.load_state_dict(sd)
+    net = net.cuda().eval()
+    x = _clip(g["clips"][0])
+    with torch.inference_mode():
+        net(x)
+    eng = net._engines[("f32", 1, (32, 224, 224))]
+    names = eng.op_names
+    # after each lateral the Slow rows hold [stage output | fused Fast channels]; the Fast tensor is the last
+    # pathway1 op of the stage (or its pooled stem)
+    checks = [("s1_fuse", "resnet.s1_fuse.conv_f2s", None)] + [
+        ("s%d_fuse" % k, "resnet.s%d_fuse.conv_f2s" % k, "resnet.s%d.pathway1_" % k) for k in (2, 3, 4)]
+    for gname, slow_op, fast_prefix in checks:
+        i = names.index(slow_op)
+        eng.run_prefix(i + 1)
+        slow = eng.activation(i).permute(0, 4, 1, 2, 3).contiguous().float().cpu()
+        assert list(slow.shape) == list(st[gname + "_slow_shape"]), gname
+        got = slow.flatten()[torch.from_numpy(st[gname + "_slow_idx"])].numpy()
+        want = st[gname + "_slow_val"]
+        assert np.abs(got - want).max() <= 1e-4 * max(1.0, float(np.abs(want).max())), gname
+        if fast_prefix:
+            j = max(k for k, n in enumerate(names) if n.startswith(fast_prefix))
+            fast = eng.activation(j).permute(0, 4, 1, 2, 3).contiguous().float().cpu()
+            assert list(fast.shape) == list(st[gname + "_fast_shape"]), gname
+            got = fast.flatten()[torch.from_numpy(st[gname + "_fast_idx"])].numpy()
+            want = st[gname + "_fast_val"]
+            assert np.abs(got - want).max() <= 1e-4 * max(1.0, float(np.abs(want).max())), gname
+
+
+def test_slowfast_batch_and_errors(sf_weights):
+    g, sd = sf_weights
+    net = SlowFast8x8(precision="f16")
+    net.load_state_dict(sd)
+    net = net.cuda().eval()
+    x = torch.cat([_clip(g["clips"][0]), _clip(g["clips"][1])])
+    with torch.inference_mode():
+        yb = net(x)["final_output"]
+        y0 = net(x[:1])["final_output"]
+    assert yb.shape == (2, 1) and torch.equal(yb[:1], y0)
+    with pytest.raises(ValueError):
+        net([x, x, x])
+    with pytest.raises(ValueError):
+        net([x[:, :, ::4], x])                  # Slow pathway must have T/alpha frames

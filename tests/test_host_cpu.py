@@ -26,6 +26,18 @@ def test_state_dict_layout_equals_reference(clf):
     assert sum(p.numel() for p in clf.parameters()) == 27225921
 
 
+def test_slowfast_state_dict_layout():
+    from af_mi355x.classifier import SlowFast8x8
+    m = SlowFast8x8()
+    lay = [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
+    assert lay == [(k, tuple(s)) for k, s, d in arch.state_dict_layout(m.spec)]
+    assert len(lay) == load_json("f5_slowfast.json")["num_keys"] == 662
+    assert sum(p.numel() for p in m.parameters()) == 33560521
+    assert m.resnet.s1_fuse.conv_f2s.weight.shape == (16, 8, 5, 1, 1)
+    assert m.resnet.s2.pathway0_res0.branch2.a.weight.shape == (64, 80, 1, 1, 1)     # 64 + 2*8 fused channels in
+    assert m.resnet.head.projection.in_features == 2304
+
+
 def test_last_linear_is_head_projection(clf):
     lin = [m for m in clf.modules() if isinstance(m, torch.nn.Linear)][-1]
     assert lin is clf.network.resnet.head.projection and lin.in_features == 2048 and lin.out_features == 1
@@ -105,7 +117,7 @@ def test_c_abi_exports_every_declared_symbol():
         assert hasattr(_lib.lib, name)
     assert _lib.lib.af_version() == 1
     import ctypes as C
-    assert C.sizeof(_lib.ConvDesc) == 21 * 4 and C.sizeof(_lib.PoolDesc) == 18 * 4
+    assert C.sizeof(_lib.ConvDesc) == 21 * 4 and C.sizeof(_lib.PoolDesc) == 19 * 4
 
 
 def test_abi_rejects_bad_arguments_without_a_gpu():

@@ -90,6 +90,29 @@ def test_full_size_logits_and_stages(golden_f1, weights0):
                 np.testing.assert_allclose(float(flat.double().abs().mean()), f2[n + "_stats"][1], rtol=1e-5)
 
 
+def test_slowfast_logits_and_stages():
+    """oracle.slowfast_forward against the reference's SlowFast-R50 (tests/golden/f5_slowfast*)."""
+    g = load_json("f5_slowfast.json")
+    st = load_npz("f5_slowfast_stages.npz")
+    spec = arch.slowfast_r50_spec()
+    assert g["num_keys"] == 662 == len(arch.state_dict_layout(spec)) and g["num_params"] == 33560521
+    sd = synth.synthetic_state_dict(spec, seed=g["weights_seed"])
+    assert synth.state_dict_sha256(sd) == g["weights_sha256"]
+    for ci, c in enumerate(g["clips"]):
+        u8 = synth.synthetic_clips_u8(c["index"] + 1, seed=c["seed"], kind=c["kind"])[c["index"]:c["index"] + 1]
+        assert synth.tensor_sha256(u8) == c["clip_sha256"]
+        x = oracle.normalize(u8)
+        logits, stages = oracle.slowfast_forward(sd, x[:, :, ::g["alpha"]], x, alpha=g["alpha"], return_stages=True)
+        assert logits.shape == (1, 1)
+        assert abs(float(logits[0, 0]) - c["logit_f32"]) <= 1e-5
+        if ci == 0:
+            for name, key in (("s1_fuse", "s1"), ("s2_fuse", "s2"), ("s3_fuse", "s3"), ("s4_fuse", "s4"), ("s5", "s5")):
+                for tag, t in zip(("slow", "fast"), stages[key]):
+                    assert list(t.shape) == list(st["%s_%s_shape" % (name, tag)]), (name, tag)
+                    got = t.flatten()[torch.from_numpy(st["%s_%s_idx" % (name, tag)])].numpy()
+                    np.testing.assert_allclose(got, st["%s_%s_val" % (name, tag)], rtol=1e-4, atol=1e-5)
+
+
 def test_checkpoint_unwrap_rules():
     base = {"resnet.a": torch.ones(1)}
     assert list(oracle.strip_checkpoint({"state_dict": {"module.resnet.a": 1}})) == ["resnet.a"]
