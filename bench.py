@@ -26,21 +26,22 @@ PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}    # dense MFMA, MI3
 HBM_PEAK_GBS = 8000.0
 
 
-def cpu_baseline(sd, u8, threads_all):
+def cpu_baseline(sd, u8, threads_all, model="i3d"):
     """The oracle (PyTorch-CPU restatement of the reference forward, pinned by tests/golden) timed on the
     host cores: a bounded sample of the same workload."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import i3d_oracle as oracle
     x = oracle.normalize(u8)
+    fwd = oracle.forward if model == "i3d" else (lambda s_, x_: oracle.slowfast_forward(s_, x_[:, :, ::8], x_))
     torch.set_num_threads(threads_all)
     with torch.no_grad():
-        oracle.forward(sd, x[:1])                                   # warm-up (first call pages oneDNN in)
+        fwd(sd, x[:1])                                              # warm-up (first call pages oneDNN in)
         t0 = time.perf_counter()
-        ref = oracle.forward(sd, x)
+        ref = fwd(sd, x)
         t_all = time.perf_counter() - t0
         torch.set_num_threads(1)
         t0 = time.perf_counter()
-        oracle.forward(sd, x[:1])
+        fwd(sd, x[:1])
         t_one = time.perf_counter() - t0
     torch.set_num_threads(threads_all)
     return ref, {"value": round(x.shape[0] / t_all, 4), "unit": "clips/s", "cores": threads_all, "kind": "port",
@@ -74,6 +75,8 @@ def main():
     ap.add_argument("--batch", type=int, default=16, help="clips per GPU")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--cpu-clips", type=int, default=4, help="clips in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--model", default="i3d", choices=["i3d", "slowfast"],
+                    help="i3d = the i3d_ori plugin (BASELINE metric); slowfast = the two-pathway SlowFast-R50 (next row)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--layers-json", default=None, help="write per-layer device times / rates to this file")
     args = ap.parse_args()
@@ -93,10 +96,20 @@ def main():
     torch.cuda.set_device(dev)
     B = args.batch
 
-    sd = synth.synthetic_state_dict(seed=0)
-    clf = Classifier(precision=args.dtype)
-    clf.network.load_state_dict(sd)
-    clf = clf.to(dev).eval()
+    if args.model == "slowfast":
+        from af_mi355x.arch import slowfast_r50_spec
+        from af_mi355x.classifier import SlowFast8x8
+        sd = synth.synthetic_state_dict(slowfast_r50_spec(), seed=0)
+        clf = SlowFast8x8(precision=args.dtype)
+        clf.load_state_dict(sd)
+        clf = clf.to(dev).eval()
+        net = clf
+    else:
+        sd = synth.synthetic_state_dict(seed=0)
+        clf = Classifier(precision=args.dtype)
+        clf.network.load_state_dict(sd)
+        clf = clf.to(dev).eval()
+        net = clf.network
     u8 = synth.synthetic_clips_u8(B, seed=2026 + rank, kind="uniform")
     x = synth.normalize_like_callers(u8.to(dev))                       # (B,3,32,224,224) fp32, channels-last strides
     gathered = torch.empty((world * B, 1), dtype=torch.float32, device=dev)
@@ -131,13 +144,14 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": "AltFreezing i3d_ori (I3D-R50) forward, batch=%d clips/GPU of 32x3x224x224, "
-                               "synthetic checkpoint W(0), model.forward(clip) on HBM-resident fp32 input" % B,
+        "config": {"workload": "%s forward, batch=%d clips/GPU of 32x3x224x224, synthetic checkpoint W(0), "
+                               "model.forward(clip) on HBM-resident fp32 input"
+                               % ("AltFreezing i3d_ori (I3D-R50)" if args.model == "i3d" else "SlowFast-R50 (alpha 8)", B),
                    "global_batch": world * B, "parallelism": "dp%d + all-gather of logits" % world},
     }
 
     if rank == 0 and world == 1:
-        eng = clf.network._engines[(args.dtype, B, (32, 224, 224))]
+        eng = net._engines[(args.dtype, B, (32, 224, 224))]
         total_macs = sum(eng.op_macs)
         line["model_tflops_per_s"] = round(2 * total_macs / B * clips_per_s / 1e12, 2)
         if not args.no_roofline:
@@ -220,7 +234,7 @@ def main():
                 cores = len(os.sched_getaffinity(0))
             except AttributeError:
                 cores = os.cpu_count() or 1
-            ref, cb = cpu_baseline(sd, u8[:n], max(1, min(cores, 16)))     # the box's CPU share for one GPU is 16
+            ref, cb = cpu_baseline(sd, u8[:n], max(1, min(cores, 16)), args.model)     # the box's CPU share for one GPU is 16
             line["cpu_baseline"] = cb
             line["max_abs_logit_err_vs_cpu_fp32"] = float((out[:n].float().cpu() - ref).abs().max())
     if rank == 0:
