@@ -23,6 +23,8 @@
 
 namespace af {
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
 struct ConvArgs {
     const char* in;
     const char* w;
@@ -365,7 +367,7 @@ __global__ __launch_bounds__(512, MINW) void conv_igemm_kernel(const ConvArgs a)
                         const long long lin0 = (nj * 2) * hw + pix;                // (n, 2j, ho, wo) in NDHWC order
 #pragma unroll
                         for (int p2 = 0; p2 < 2; ++p2) {
-                            const uint4 rraw = *reinterpret_cast<const uint4*>(a.res + ((lin0 + p2 * hw) * a.Cout + ch0) * ES);
+                            const uint4 rraw = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.res + ((lin0 + p2 * hw) * a.Cout + ch0) * ES)));
                             const typename E::type* re = reinterpret_cast<const typename E::type*>(&rraw);
 #pragma unroll
                             for (int e = 0; e < EPC; ++e) v[p2][e] += E::to_f32(re[e]);
@@ -379,7 +381,7 @@ __global__ __launch_bounds__(512, MINW) void conv_igemm_kernel(const ConvArgs a)
                         if (a.relu) { x0 = fmaxf(x0, 0.f); x1 = fmaxf(x1, 0.f); }
                         oe[e] = E::from_f32((x1 > x0 || x1 != x1) ? x1 : x0);      // NaN propagates like ATen's max_pool
                     }
-                    *reinterpret_cast<uint4*>(a.out + ((m >> 1) * a.out_ld + ch0) * ES) = o;
+                    __builtin_nontemporal_store(__builtin_bit_cast(u32x4, o), reinterpret_cast<u32x4*>(a.out + ((m >> 1) * a.out_ld + ch0) * ES));
                 }
             }
         } else {
@@ -395,7 +397,7 @@ __global__ __launch_bounds__(512, MINW) void conv_igemm_kernel(const ConvArgs a)
                 }
                 if (m < a.M && ch0 < a.Cout) {          // channel groups beyond Cout are padding
                     if (a.res) {
-                        const uint4 rraw = *reinterpret_cast<const uint4*>(a.res + (m * a.Cout + ch0) * ES);
+                        const uint4 rraw = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.res + (m * a.Cout + ch0) * ES)));
                         const typename E::type* re = reinterpret_cast<const typename E::type*>(&rraw);
     #pragma unroll
                         for (int e = 0; e < EPC; ++e) v[e] += E::to_f32(re[e]);
@@ -408,7 +410,7 @@ __global__ __launch_bounds__(512, MINW) void conv_igemm_kernel(const ConvArgs a)
                     typename E::type* oe = reinterpret_cast<typename E::type*>(&o);
     #pragma unroll
                     for (int e = 0; e < EPC; ++e) oe[e] = E::from_f32(v[e]);
-                    *reinterpret_cast<uint4*>(a.out + (m * a.out_ld + ch0) * ES) = o;
+                    __builtin_nontemporal_store(__builtin_bit_cast(u32x4, o), reinterpret_cast<u32x4*>(a.out + (m * a.out_ld + ch0) * ES));
                 }
             }
         }

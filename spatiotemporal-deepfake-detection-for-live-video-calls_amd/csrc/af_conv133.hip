@@ -150,7 +150,8 @@ __global__ __launch_bounds__(512, 2) void conv133_c64_kernel(const C133Args a) {
                     typename E::type* oe = reinterpret_cast<typename E::type*>(&o);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { oe[e] = E::from_f32(v0[e]); oe[4 + e] = E::from_f32(v1[e]); }
-                    *reinterpret_cast<uint4*>(a.out + (((long long)frame * a.H + h0 + r) * a.W + (c - 1)) * 128 + (nh * 32 + pcc) * 2) = o;
+                    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+                    __builtin_nontemporal_store(__builtin_bit_cast(u32x4, o), reinterpret_cast<u32x4*>(a.out + (((long long)frame * a.H + h0 + r) * a.W + (c - 1)) * 128 + (nh * 32 + pcc) * 2));
                 }
                 __builtin_amdgcn_wave_barrier();
             }
