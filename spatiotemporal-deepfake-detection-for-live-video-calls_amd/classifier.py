@@ -159,6 +159,8 @@ class I3D8x8(_HipNetwork):
         assert not freeze_backbone
         x = self._check_input(images)
         B, _, T, H, W = x.shape
+        if B == 0:                                   # an empty batch is an empty answer (no launch)
+            return {"final_output": x.new_zeros((0, self.spec.num_classes))}
         with torch.cuda.device(x.device):
             eng = self._engine(self._select_dtype(), B, (T, H, W), x.device)
             logits, pooled = eng.run_f32(x)

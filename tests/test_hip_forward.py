@@ -172,6 +172,30 @@ def test_reload_repacks_weights(clf32, ckpt_path, golden_f1):
     assert abs(y1 - y0) > 1e-3
 
 
+def test_edge_inputs(clf32, weights0):
+    """empty batch; odd batch; a crop larger than 224 (the reference then returns one logit per head position,
+    head_helper.py:54,94); too few frames for the head pool -> error; fp16 input tensor."""
+    with torch.inference_mode():
+        y = clf32(torch.zeros((0, 3, 32, 224, 224), device="cuda"))["final_output"]
+        assert y.shape == (0, 1)
+        u8 = synth.synthetic_clips_u8(3, seed=5, kind="smooth")
+        x3 = synth.normalize_like_callers(u8).cuda()
+        y3 = clf32(x3)["final_output"]
+        y1 = clf32(x3[2:3])["final_output"]
+        assert y3.shape == (3, 1) and torch.equal(y3[2:3], y1)
+        yh = clf32(x3[:1].half())["final_output"]                      # fp16 tensor in: promoted, not rejected
+        assert abs(float(yh[0, 0]) - float(y3[0, 0])) < 5e-3
+        # 256x256 crop -> s5 is 8x8 -> AvgPool3d([16,7,7], stride 1) leaves 2x2 positions -> (B, 4) logits
+        u8b = synth.synthetic_clips_u8(1, seed=6, kind="smooth", size=256)
+        xb = synth.normalize_like_callers(u8b)
+        got = clf32(xb.cuda())["final_output"].cpu()
+        want = oracle.forward(weights0, xb, num_frames=32, crop=224)
+        assert got.shape == want.shape == (1, 4)
+        assert (got - want).abs().max().item() <= 2e-4
+        with pytest.raises(ValueError, match="too small"):
+            clf32(torch.zeros((1, 3, 16, 224, 224), device="cuda"))
+
+
 def test_small_network_vs_oracle_all_dtypes():
     """Shrunken clip (8 frames, 64x64, head pool [4,2,2]) through all 53 convs, every dtype, vs the oracle."""
     clip_size, size = 8, 64
