@@ -14,4 +14,5 @@ tail -1 $OUT/bench.log > $OUT/bench.json
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --dtype $DT --cpu-clips 0 --no-roofline > $OUT/trace.log 2>&1; echo "trace rc=$?"
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ROOT/bench.py --dtype $DT --cpu-clips 0 --steps 2 --warmup 1 --no-roofline > $OUT/pmc_fetch.log 2>&1; echo "fetch rc=$?"
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mfma -- python3 $ROOT/bench.py --dtype $DT --cpu-clips 0 --steps 2 --warmup 1 --no-roofline > $OUT/pmc_mfma.log 2>&1; echo "mfma rc=$?"
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ROOT/bench.py --dtype $DT --cpu-clips 0 --steps 2 --warmup 1 --no-roofline > $OUT/pmc_write.log 2>&1; echo "write rc=$?"

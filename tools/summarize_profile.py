@@ -20,14 +20,16 @@ def per_kernel(path, counter):
     seen = {}
     for r in rows:
         if r["Counter_Name"] == counter:
-            seen[r["Dispatch_Id"]] = (r["Kernel_Name"], float(r["Counter_Value"]))
+            seen[r["Dispatch_Id"]] = (r["Kernel_Name"], float(r["Counter_Value"]),
+                                      (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9)
     agg = collections.OrderedDict()
-    for name, v in seen.values():
+    for name, v, t in seen.values():
         if "af::" not in name:
             continue
-        a = agg.setdefault(name, [0, 0.0])
+        a = agg.setdefault(name, [0, 0.0, 0.0])
         a[0] += 1
         a[1] += v
+        a[2] += t
     return agg
 
 
@@ -44,13 +46,22 @@ def main():
     if f and w:
         fetch, write = per_kernel(f[0], "FETCH_SIZE"), per_kernel(w[0], "WRITE_SIZE")
         out = {}
+        m = glob.glob(os.path.join(src, "pmc_mfma", "*", "*counter_collection.csv"))
+        mfma = per_kernel(m[0], "SQ_VALU_MFMA_BUSY_CYCLES") if m else {}
+        gui = per_kernel(m[0], "GRBM_GUI_ACTIVE") if m else {}
         for k in fetch:
-            n, fs = fetch[k]
-            ws = write.get(k, [n, 0.0])[1]
+            n, fs, tf = fetch[k]
+            ws = write.get(k, [n, 0.0, 0.0])[1]
             out[k] = {"launches_profiled": n,
                       "hbm_read_bytes_per_launch": 2 * fs * 1024 / n,
                       "hbm_write_bytes_per_launch": ws * 1024 / n,
-                      "hbm_bytes_per_launch": (2 * fs + ws) * 1024 / n}
+                      "hbm_bytes_per_launch": (2 * fs + ws) * 1024 / n,
+                      # bytes of both passes over the kernel time of the FETCH pass (profiled clocks run ~3 % low)
+                      "hbm_GBps": (2 * fs + ws) * 1024 / tf / 1e9 if tf else None,
+                      "hbm_frac_of_8TBps": (2 * fs + ws) * 1024 / tf / 8e12 if tf else None}
+            if k in mfma and k in gui and gui[k][1]:
+                # SQ_VALU_MFMA_BUSY_CYCLES: busy cycles summed over SIMDs; GRBM_GUI_ACTIVE: summed over the 8 XCDs
+                out[k]["mfma_busy_frac"] = mfma[k][1] / (gui[k][1] / 8.0 * 256 * 4)
         json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), 2x FETCH correction for gfx950",
                    "kernels": out}, open("profiles/%s_traffic.json" % name, "w"), indent=1)
     print("wrote profiles/%s_*" % name)
