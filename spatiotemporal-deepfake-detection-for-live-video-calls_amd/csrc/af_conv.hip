@@ -12,11 +12,13 @@
 //     K-step of one tile row is one contiguous 128-byte run = 8 x 16-byte chunks.
 //   * LDS tiles are [row][8 chunks] with chunk ^= (row & 7): conflict-free ds_write_b128 from the
 //     staging pass and conflict-free ds_read_b128 for the MFMA fragments (bank math in DESIGN.md).
-//   * operands go HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4, 16 B per lane, no VGPR staging and
+//   * operands go HBM/L2 -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds, 16 B per lane, no VGPR staging and
 //     no ds_write): one wave-instruction fills 8 tile rows; the LDS image is lane-linear, so the
 //     swizzle is applied on the SOURCE side (lane (row, slot) fetches chunk slot ^ (row & 7)).
-//   * zero padding: out-of-bounds taps fetch from a 128-byte zero page instead of the activation
-//     (per-row validity bit per tap, computed once); no halo in HBM, no branch in the K loop.
+//     Addressing is buffer-style: a per-workgroup descriptor, a per-lane 32-bit row offset that never
+//     changes, and the K-step's (tap, channel-slab) offset in an SGPR - no address VALU in the K loop.
+//   * zero padding: an out-of-bounds tap gets a per-lane offset beyond the descriptor's range and the
+//     hardware returns zeros (per-row validity bit per tap, computed once); no halo in HBM, no branch.
 //   * pipeline: 3-slot LDS ring, K-steps s+1 and s+2 in flight while step s is multiplied; one raw
 //     s_barrier per K-step; explicit counted s_waitcnt vmcnt (hipcc does not see the DMA loads).
 #include "af_common.h"
@@ -49,37 +51,50 @@ struct ConvArgs {
     int T2, H2, W2, Cin2, Cin2P, st2, sh2, sw2, kpt2;
 };
 
-// 128 bytes of zeros in HBM: the source of every out-of-bounds (padding) tap, so that zero padding
-// costs no branch and no LDS write of its own - the LDS-DMA simply fetches zeros.
-__device__ uint4 g_zero_page[8];
-
-// one 16-byte-per-lane LDS-DMA: LDS[lds_base + lane*16 .. +16) <- *gsrc (per-lane global address).
-// hipcc does not count this load: every wait on it is an explicit s_waitcnt vmcnt(N) below.
-__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_base) {
+// one 16-byte-per-lane LDS-DMA: LDS[lds_base + lane*16 .. +16) <- desc.base[voff + soff .. +16); a lane whose
+// voff is outside the descriptor's 2 GiB window (kOutOfRange) gets zeros - that is how padding taps, rows beyond M
+// and channel tails are filled.  hipcc does not count this load: every wait on it is an explicit s_waitcnt vmcnt(N).
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned kOutOfRange = 0x80000000u;
+__device__ __forceinline__ void blds16(unsigned voff, const i32x4& desc, int soff, unsigned lds_base) {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_base) : "memory");
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(desc), "s"(lds_base), "s"(soff) : "memory");
+}
+// raw buffer descriptor over [base, base + 2 GiB): stride 0, no swizzle, 32-bit data format
+__device__ __forceinline__ i32x4 make_desc(const char* base) {
+    const unsigned long long b = (unsigned long long)base;
+    i32x4 d;
+    d[0] = __builtin_amdgcn_readfirstlane((int)(b & 0xffffffffu));
+    d[1] = __builtin_amdgcn_readfirstlane((int)((b >> 32) & 0xffffu));
+    d[2] = (int)kOutOfRange;
+    d[3] = 0x00020000;
+    return d;
 }
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-// 8 waves (512 threads); wave (wn, wm) owns a (BN/WN) x (BM/WM) sub-tile of 16x16 MFMA tiles.
+// NW = WN*WM*KS = 8 waves (512 threads); wave (wn, wm) owns a (BN/WN) x (BM/WM) sub-tile of 16x16
+// MFMA tiles.
 // KS = 2 splits each stage's K between wave groups 0-3 / 4-7 (used for Cout = 64: every wave then owns a
 // 64x64 sub-tile, halving LDS fragment traffic per MFMA; the two partial sums meet in LDS after the loop).
 // DUAL compiles in the second K segment (projection shortcut accumulated into the same tile).
 template <int DT, int BN, int BM, int WN, int WM, int KS, int NSTAGE, int MINW, bool DUAL>
-__global__ __launch_bounds__(512, MINW) void conv_igemm_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(WN * WM * KS * 64, MINW) void conv_igemm_kernel(const ConvArgs a) {
     typedef Elem<DT> E;
     constexpr int EPC = E::EPC;            // elements per 16-byte chunk
     constexpr int ES = 16 / EPC;           // bytes per element
     constexpr int WTN = BN / WN, WTM = BM / WM;
     constexpr int TN = WTN / 16, TM = WTM / 16;
-    constexpr int RW = BN / 64, RX = BM / 64;        // tile rows (= LDS-DMA instructions) per thread per stage
+    constexpr int NW = WN * WM * KS;                 // waves per workgroup
+    constexpr int GR = NW * 8;                       // tile rows one pass of the workgroup stages (8 lanes per row)
+    constexpr int RW = BN / GR, RX = BM / GR;        // tile rows (= LDS-DMA instructions) per thread per stage
     constexpr int PER_WAVE = RW + RX;                // LDS-DMA instructions a wave issues per stage
     constexpr int STAGE_BYTES = (BN + BM) * 128;
-    static_assert(WN * WM * KS == 8 && (KS == 1 || KS == 2), "8 waves per workgroup");
+    static_assert(NW == 8 && (KS == 1 || KS == 2) && BN % GR == 0 && BM % GR == 0, "8 waves per workgroup");
     constexpr bool LEAN = MINW >= 4;
-    static_assert(NSTAGE == 3, "the vmcnt bookkeeping below is written for a 3-slot ring");
+    typedef Mma<DT> MMA;
+    static_assert(NSTAGE == 3 || (NSTAGE == 2 && !LEAN && KS == 1), "ring depth of the pipelined loop: 3 or 2 slots");
 
     extern __shared__ uint4 smem[];
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
@@ -95,43 +110,51 @@ __global__ __launch_bounds__(512, MINW) void conv_igemm_kernel(const ConvArgs a)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kgroup = wave / (WN * WM), wsub = wave % (WN * WM);
     const int wn = wsub % WN, wm = wsub / WN;
-    const int lrow = tid >> 3;                         // 0..63: row inside a 64-row group
+    const int lrow = tid >> 3;                         // 0..GR-1: row inside a GR-row group
     const int chunk = (tid & 7) ^ (lrow & 7);          // source chunk that lands in LDS slot (tid & 7)
 
-    // ---- per-thread staging rows: global row pointers + a validity bit per tap
+    // ---- per-thread staging rows: a 32-bit offset from the workgroup's origin + a validity bit per tap.
+    // The origin is the (padding-shifted) first input element of tile row 0; every other row of the tile lies at a
+    // non-negative offset from it (row offsets grow with (n, to, ho, wo), also in the pool-fused row order).
     const int taps = a.kt * a.kh * a.kw;
     const long long m0 = (long long)tile_m * BM;
-    const char* xptr[RX];
-    const char* x2ptr[RX];
+    auto row_offsets = [&](long long m, long long& off1, long long& off2, unsigned& mask) {
+        // tile row -> output position.  With the temporal pool fused, rows are ordered (n, to/2, ho, wo, to%2):
+        // the two frames a pool window spans are ADJACENT rows of the tile (the epilogue takes their max)
+        const long long mq = a.tpool ? (m >> 1) : m;
+        int wo = (int)(mq % a.Wo); long long t1 = mq / a.Wo;
+        int ho = (int)(t1 % a.Ho); long long t2 = t1 / a.Ho;
+        const int tdiv = a.tpool ? (a.To >> 1) : a.To;
+        int to = (int)(t2 % tdiv); long long n = t2 / tdiv;
+        if (a.tpool) to = 2 * to + (int)(m & 1);
+        const int ti0 = to * a.st - a.pt, hi0 = ho * a.sh - a.ph, wi0 = wo * a.sw - a.pw;
+        off1 = ((((n * a.T + ti0) * a.H + hi0) * a.W + wi0) * a.Cin) * ES;
+        off2 = DUAL ? ((((n * a.T2 + to * a.st2) * a.H2 + ho * a.sh2) * a.W2 + wo * a.sw2) * a.Cin2) * ES : 0;
+        mask = 1u << 31;
+        int tap = 0;
+        for (int dt = 0; dt < a.kt; ++dt)
+            for (int dh = 0; dh < a.kh; ++dh)
+                for (int dw = 0; dw < a.kw; ++dw, ++tap) {
+                    bool ok = (unsigned)(ti0 + dt) < (unsigned)a.T && (unsigned)(hi0 + dh) < (unsigned)a.H &&
+                              (unsigned)(wi0 + dw) < (unsigned)a.W;
+                    mask |= (ok ? 1u : 0u) << tap;
+                }
+    };
+    long long org1, org2; unsigned org_mask;
+    row_offsets(m0, org1, org2, org_mask);               // uniform: tile row 0 always exists
+    const i32x4 xdesc = make_desc(a.in + org1);
+    const i32x4 x2desc = make_desc((DUAL ? a.in2 : a.in) + org2);
+    unsigned xoff[RX], x2off[RX];
     unsigned xmask[RX];                                 // bit t: tap t in bounds; bit 31: row < M
 #pragma unroll
     for (int i = 0; i < RX; ++i) {
-        long long m = m0 + lrow + 64 * i;
-        xmask[i] = 0;
-        xptr[i] = a.in;
-        x2ptr[i] = a.in;
+        const long long m = m0 + lrow + GR * i;
+        xmask[i] = 0; xoff[i] = kOutOfRange; x2off[i] = kOutOfRange;
         if (m < a.M) {
-            // tile row -> output position.  With the temporal pool fused, rows are ordered (n, to/2, ho, wo, to%2):
-            // the two frames a pool window spans are ADJACENT rows of the tile (the epilogue takes their max)
-            const long long mq = a.tpool ? (m >> 1) : m;
-            int wo = (int)(mq % a.Wo); long long t1 = mq / a.Wo;
-            int ho = (int)(t1 % a.Ho); long long t2 = t1 / a.Ho;
-            const int tdiv = a.tpool ? (a.To >> 1) : a.To;
-            int to = (int)(t2 % tdiv); long long n = t2 / tdiv;
-            if (a.tpool) to = 2 * to + (int)(m & 1);
-            const int ti0 = to * a.st - a.pt, hi0 = ho * a.sh - a.ph, wi0 = wo * a.sw - a.pw;
-            xptr[i] = a.in + ((((n * a.T + ti0) * a.H + hi0) * a.W + wi0) * a.Cin + chunk * EPC) * ES;
-            xmask[i] = 1u << 31;
-            if (DUAL)
-                x2ptr[i] = a.in2 + ((((n * a.T2 + to * a.st2) * a.H2 + ho * a.sh2) * a.W2 + wo * a.sw2) * a.Cin2 + chunk * EPC) * ES;
-            int tap = 0;
-            for (int dt = 0; dt < a.kt; ++dt)
-                for (int dh = 0; dh < a.kh; ++dh)
-                    for (int dw = 0; dw < a.kw; ++dw, ++tap) {
-                        bool ok = (unsigned)(ti0 + dt) < (unsigned)a.T && (unsigned)(hi0 + dh) < (unsigned)a.H &&
-                                  (unsigned)(wi0 + dw) < (unsigned)a.W;
-                        xmask[i] |= (ok ? 1u : 0u) << tap;
-                    }
+            long long o1, o2;
+            row_offsets(m, o1, o2, xmask[i]);
+            xoff[i] = (unsigned)(o1 - org1) + chunk * 16;       // < 2 GiB (host-checked span)
+            x2off[i] = (unsigned)(o2 - org2) + chunk * 16;
         }
     }
     const long long Kw = (long long)taps * a.CinP;     // weight row length (elements, zero-padded per tap)
@@ -140,14 +163,14 @@ __global__ __launch_bounds__(512, MINW) void conv_igemm_kernel(const ConvArgs a)
     constexpr int BKE = 8 * EPC;
     const bool clast = chunk * EPC < a.Cin - (a.kpt - 1) * BKE;
     const bool clast2 = DUAL && chunk * EPC < a.Cin2 - (a.kpt2 - 1) * BKE;
-    const char* wptr[RW];
-    const char* w2ptr[RW];
+    const i32x4 wdesc = make_desc(a.w + (long long)tile_n * BN * Kw * ES);
+    const i32x4 w2desc = make_desc(a.w2 + (long long)tile_n * BN * a.Cin2P * ES);
+    unsigned woff[RW], w2off[RW];
 #pragma unroll
     for (int i = 0; i < RW; ++i) {
-        wptr[i] = a.w + ((tile_n * BN + lrow + 64 * i) * Kw + chunk * EPC) * ES;
-        w2ptr[i] = a.w2 + ((long long)(tile_n * BN + lrow + 64 * i) * a.Cin2P + chunk * EPC) * ES;
+        woff[i] = (unsigned)(((lrow + GR * i) * Kw + chunk * EPC) * ES);          // < 2 GiB (host-checked weight size)
+        w2off[i] = (unsigned)(((long long)(lrow + GR * i) * a.Cin2P + chunk * EPC) * ES);
     }
-    const char* zero = reinterpret_cast<const char*>(g_zero_page);
 
     // ---- LDS-DMA producer: stage `st` <- K-step (tap, kc), kc fastest: the 64-channel slabs of one tap are
     // consecutive 128-byte pieces of the same NDHWC rows, so a row's channels are fetched in back-to-back steps
@@ -156,17 +179,17 @@ __global__ __launch_bounds__(512, MINW) void conv_igemm_kernel(const ConvArgs a)
     // at a time so that the main loop can tuck them between MFMA groups.
     int dt = 0, dh = 0, dw = 0, kc = 0, tap = 0;
     auto issue_piece = [&](int st, int g) {
-        const unsigned base = lds0 + st * STAGE_BYTES + wave * (8 * 128) + g * (64 * 128);
+        const unsigned base = lds0 + st * STAGE_BYTES + wave * (8 * 128) + g * (GR * 128);
         if (DUAL && tap >= taps) {                               // second segment (projection shortcut)
             const int off2 = kc * 128;
-            if (g < RW) glds16(w2ptr[g] + off2, base);
-            else glds16(((xmask[g - RW] >> 31) && (kc + 1 < a.kpt2 || clast2)) ? x2ptr[g - RW] + off2 : zero, base);
+            if (g < RW) blds16(w2off[g], w2desc, off2, base);
+            else blds16(((xmask[g - RW] >> 31) && (kc + 1 < a.kpt2 || clast2)) ? x2off[g - RW] : kOutOfRange, x2desc, off2, base);
         } else if (g < RW) {
-            glds16(wptr[g] + (long long)(tap * a.CinP * ES + kc * 128), base);
+            blds16(woff[g], wdesc, tap * a.CinP * ES + kc * 128, base);
         } else {
-            const int xoff = ((dt * a.H + dh) * a.W + dw) * a.Cin * ES + kc * 128;   // < 2^31 (host-checked)
+            const int xsoff = ((dt * a.H + dh) * a.W + dw) * a.Cin * ES + kc * 128;   // < 2^31 (host-checked)
             const bool ok = ((xmask[g - RW] >> tap) & 1u) && (kc + 1 < a.kpt || clast);
-            glds16(ok ? xptr[g - RW] + xoff : zero, base);
+            blds16(ok ? xoff[g - RW] : kOutOfRange, xdesc, xsoff, base);
         }
     };
     auto advance = [&]() {
@@ -214,7 +237,7 @@ __global__ __launch_bounds__(512, MINW) void conv_igemm_kernel(const ConvArgs a)
 #pragma unroll
                 for (int i = 0; i < TN; ++i)
 #pragma unroll
-                    for (int j = 0; j < TM; ++j) Mma<DT>::run(af[i], bf[j], acc[i][j]);
+                    for (int j = 0; j < TM; ++j) MMA::run(af[i], bf[j], acc[i][j]);
             }
         };
         if (LEAN && a.ring == 2) {
@@ -242,8 +265,8 @@ __global__ __launch_bounds__(512, MINW) void conv_igemm_kernel(const ConvArgs a)
         // MFMA-bound variants: software-pipelined by k-HALVES.  The fragments of a half are read from LDS while
         // the MFMAs of the previous half run, so the matrix pipe never waits for the LDS fill that follows a
         // barrier; the barrier (+ the counted vmcnt that makes stage s+1 visible) sits between the two MFMA
-        // groups of a stage, and the LDS-DMA pieces of stage s+2 (SALU m0 juggling, address VALU, ~60-cycle VMEM
-        // issue each) are tucked between the MFMAs of the first group.  sched_barrier pins the interleave.
+        // groups of a stage, and the LDS-DMA pieces of the look-ahead stage are tucked between the MFMAs of the
+        // second group.
         constexpr int NTH = TN * TM;                              // tile products per k-half
         constexpr int MPG = (NTH + PER_WAVE - 1) / PER_WAVE;      // products between two DMA pieces
         uint4 a0[TN], b0[TM], a1[TN], b1[TM];
@@ -256,49 +279,91 @@ __global__ __launch_bounds__(512, MINW) void conv_igemm_kernel(const ConvArgs a)
 #pragma unroll
             for (int j = 0; j < TM; ++j) bf[j] = xs[j * 16 * 8 + c];
         };
-        wait_vmcnt<0>();                                          // prologue: stage 0 (and 1) landed
-        __builtin_amdgcn_s_barrier();
-        read_half(a0, b0, 0, 0);
         int st = 0;
-        // all stages but the last (the last one is peeled: no barrier / look-ahead read in it, and - just as
-        // important - no control-flow merge in the steady-state body, which would make hipcc's LDS wait counts
-        // conservative and stall the second MFMA group on the look-ahead reads)
-        for (int s = 0; s + 1 < S; ++s) {
-            const bool refill = s + 2 < S;                        // slot (s+2)%3 == (s-1)%3: its last reads were
-            const int nst = st == 0 ? 2 : st - 1;                 // retired before the previous mid-step barrier
-            const int st1 = st == 2 ? 0 : st + 1;
-            read_half(a1, b1, st, 1);
-            // ---- first half: MFMA(a0,b0) with the DMA pieces of stage s+2 in the gaps
-#pragma unroll
-            for (int g = 0; g < PER_WAVE; ++g) {
-                __builtin_amdgcn_sched_barrier(0);
-                if (refill) issue_piece(nst, g);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int t = g * MPG; t < (g + 1) * MPG && t < NTH; ++t) Mma<DT>::run(a0[t / TM], b0[t % TM], acc[t / TM][t % TM]);
-            }
-#pragma unroll
-            for (int t = PER_WAVE * MPG; t < NTH; ++t) Mma<DT>::run(a0[t / TM], b0[t % TM], acc[t / TM][t % TM]);
-            if (refill) advance();
-            __builtin_amdgcn_sched_barrier(0);
-            // this wave's reads of stage s are back (they were issued a whole MFMA group ago) and its pieces of
-            // stage s+1 have landed; after the barrier that holds for every wave
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (refill) wait_vmcnt<PER_WAVE>(); else wait_vmcnt<0>();
+        if (NSTAGE == 2) {
+            // two slots (the 256x256 tile: 64 KB per stage); stage s lives in slot s & 1.  Once the mid-step barrier
+            // of stage s has passed, every fragment of stage s sits in registers, so its slot is refilled with stage
+            // s+2 during the SECOND MFMA group; that stage is needed at the mid-step barrier of s+1.
+            if (S > 1) wait_vmcnt<PER_WAVE>(); else wait_vmcnt<0>();         // prologue: stage 0 landed
             __builtin_amdgcn_s_barrier();
-            read_half(a0, b0, st1, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            // ---- second half: MFMA(a1,b1) runs under the LDS reads just issued
+            read_half(a0, b0, 0, 0);
+            // all stages but the last (the last one is peeled: no barrier / look-ahead read in it, and - just as
+            // important - no control-flow merge in the steady-state body, which would make hipcc's LDS wait counts
+            // conservative and stall the second MFMA group on the look-ahead reads)
+            for (int s = 0; s + 1 < S; ++s) {
+                const bool refill = s + 2 < S;
+                const int st1 = st ^ 1;
+                read_half(a1, b1, st, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- first half: MFMA(a0,b0) runs under the LDS reads just issued
 #pragma unroll
-            for (int t = 0; t < NTH; ++t) Mma<DT>::run(a1[t / TM], b1[t % TM], acc[t / TM][t % TM]);
-            __builtin_amdgcn_sched_barrier(0);
-            st = st1;
+                for (int t = 0; t < NTH; ++t) MMA::run(a0[t / TM], b0[t % TM], acc[t / TM][t % TM]);
+                __builtin_amdgcn_sched_barrier(0);
+                // this wave's reads of stage s are back and its pieces of stage s+1 (the only one in flight) have
+                // landed; after the barrier that holds for every wave
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                wait_vmcnt<0>();
+                __builtin_amdgcn_s_barrier();
+                read_half(a0, b0, st1, 0);
+                // ---- second half: MFMA(a1,b1) with the DMA pieces of stage s+2 in the gaps; sched_barrier pins the interleave
+#pragma unroll
+                for (int g = 0; g < PER_WAVE; ++g) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (refill) issue_piece(st, g);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int t = g * MPG; t < (g + 1) * MPG && t < NTH; ++t) MMA::run(a1[t / TM], b1[t % TM], acc[t / TM][t % TM]);
+                }
+#pragma unroll
+                for (int t = PER_WAVE * MPG; t < NTH; ++t) MMA::run(a1[t / TM], b1[t % TM], acc[t / TM][t % TM]);
+                if (refill) advance();
+                __builtin_amdgcn_sched_barrier(0);
+                st = st1;
+            }
+        } else {
+            wait_vmcnt<0>();                                          // prologue: stage 0 (and 1) landed
+            __builtin_amdgcn_s_barrier();
+            read_half(a0, b0, 0, 0);
+            // all stages but the last (the last one is peeled: no barrier / look-ahead read in it, and - just as
+            // important - no control-flow merge in the steady-state body, which would make hipcc's LDS wait counts
+            // conservative and stall the second MFMA group on the look-ahead reads)
+            for (int s = 0; s + 1 < S; ++s) {
+                const bool refill = s + 2 < S;                        // slot (s+2)%3 == (s-1)%3: its last reads were
+                const int nst = st == 0 ? 2 : st - 1;                 // retired before the previous mid-step barrier
+                const int st1 = st == 2 ? 0 : st + 1;
+                read_half(a1, b1, st, 1);
+                // ---- first half: MFMA(a0,b0) with the DMA pieces of stage s+2 in the gaps
+#pragma unroll
+                for (int g = 0; g < PER_WAVE; ++g) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (refill) issue_piece(nst, g);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int t = g * MPG; t < (g + 1) * MPG && t < NTH; ++t) MMA::run(a0[t / TM], b0[t % TM], acc[t / TM][t % TM]);
+                }
+#pragma unroll
+                for (int t = PER_WAVE * MPG; t < NTH; ++t) MMA::run(a0[t / TM], b0[t % TM], acc[t / TM][t % TM]);
+                if (refill) advance();
+                __builtin_amdgcn_sched_barrier(0);
+                // this wave's reads of stage s are back (they were issued a whole MFMA group ago) and its pieces of
+                // stage s+1 have landed; after the barrier that holds for every wave
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (refill) wait_vmcnt<PER_WAVE>(); else wait_vmcnt<0>();
+                __builtin_amdgcn_s_barrier();
+                read_half(a0, b0, st1, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- second half: MFMA(a1,b1) runs under the LDS reads just issued
+#pragma unroll
+                for (int t = 0; t < NTH; ++t) MMA::run(a1[t / TM], b1[t % TM], acc[t / TM][t % TM]);
+                __builtin_amdgcn_sched_barrier(0);
+                st = st1;
+            }
         }
         read_half(a1, b1, st, 1);                                 // last stage
 #pragma unroll
-        for (int t = 0; t < NTH; ++t) Mma<DT>::run(a0[t / TM], b0[t % TM], acc[t / TM][t % TM]);
+        for (int t = 0; t < NTH; ++t) MMA::run(a0[t / TM], b0[t % TM], acc[t / TM][t % TM]);
 #pragma unroll
-        for (int t = 0; t < NTH; ++t) Mma<DT>::run(a1[t / TM], b1[t % TM], acc[t / TM][t % TM]);
+        for (int t = 0; t < NTH; ++t) MMA::run(a1[t / TM], b1[t % TM], acc[t / TM][t % TM]);
     }
 
     // ---- epilogue.  The MFMA accumulator holds 4 consecutive channels of one position per lane: fine for
@@ -326,7 +391,7 @@ __global__ __launch_bounds__(512, MINW) void conv_igemm_kernel(const ConvArgs a)
         patch_off = WN * WM * TN * TM * 64 * 4;        // patches live above the reduction buffer
     }
     constexpr int PROW = WTN + 4;                      // patch row stride in floats (pad: conflict-free b128 writes)
-    constexpr int HALVES = TM >= 2 ? 2 : 1;            // the patch holds half the sub-tile at a time (LDS footprint)
+    constexpr int HALVES = TM >= 8 ? 4 : TM >= 2 ? 2 : 1;   // the patch holds a slice of the sub-tile at a time (LDS footprint)
     constexpr int TMH = TM / HALVES, PROWS = TMH * 16;
     float* patch = reinterpret_cast<float*>(smem) + patch_off + wsub * (PROWS * PROW);
     constexpr int LPR = WTN / EPC;                     // lanes per output row (16 bytes each)
@@ -390,7 +455,7 @@ __global__ __launch_bounds__(512, MINW) void conv_igemm_kernel(const ConvArgs a)
                 const int row = it * RPI + rr;
                 const long long m = m0 + wm * WTM + hf * PROWS + row;
                 float v[EPC];
-    #pragma unroll
+#pragma unroll
                 for (int e = 0; e < EPC; e += 4) {
                     const f32x4 t = *reinterpret_cast<const f32x4*>(patch + row * PROW + cc + e);
                     v[e] = t[0]; v[e + 1] = t[1]; v[e + 2] = t[2]; v[e + 3] = t[3];
@@ -399,16 +464,16 @@ __global__ __launch_bounds__(512, MINW) void conv_igemm_kernel(const ConvArgs a)
                     if (a.res) {
                         const uint4 rraw = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.res + (m * a.Cout + ch0) * ES)));
                         const typename E::type* re = reinterpret_cast<const typename E::type*>(&rraw);
-    #pragma unroll
+#pragma unroll
                         for (int e = 0; e < EPC; ++e) v[e] += E::to_f32(re[e]);
                     }
                     if (a.relu) {
-    #pragma unroll
+#pragma unroll
                         for (int e = 0; e < EPC; ++e) v[e] = fmaxf(v[e], 0.f);
                     }
                     uint4 o;
                     typename E::type* oe = reinterpret_cast<typename E::type*>(&o);
-    #pragma unroll
+#pragma unroll
                     for (int e = 0; e < EPC; ++e) oe[e] = E::from_f32(v[e]);
                     __builtin_nontemporal_store(__builtin_bit_cast(u32x4, o), reinterpret_cast<u32x4*>(a.out + (m * a.out_ld + ch0) * ES));
                 }
@@ -418,16 +483,15 @@ __global__ __launch_bounds__(512, MINW) void conv_igemm_kernel(const ConvArgs a)
     }
 }
 
-template <int DT, int BN, int BM, int WN, int WM, int KS, int MINW, bool DUAL>
+template <int DT, int BN, int BM, int WN, int WM, int KS, int MINW, bool DUAL, int NSTAGE = 3>
 static int launch(const ConvArgs& a, hipStream_t stream) {
-    constexpr int NSTAGE = 3;
     const long long tiles_m = (a.M + BM - 1) / BM;
     const long long blocks = tiles_m * a.tiles_n;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return set_error(AF_ERR_ARG, "conv: grid of %lld workgroups", blocks);
     // LDS actually needed: the ring slots this layer's K loop touches, or the epilogue patches
     constexpr int TMv = BM / WM / 16;
     constexpr int red_bytes = KS == 2 ? WN * WM * (BN / WN / 16) * TMv * 64 * 16 : 0;
-    constexpr int patch_bytes = red_bytes + WN * WM * ((TMv >= 2 ? TMv / 2 : TMv) * 16) * (BN / WN + 4) * 4;
+    constexpr int patch_bytes = red_bytes + WN * WM * ((TMv >= 8 ? TMv / 4 : TMv >= 2 ? TMv / 2 : TMv) * 16) * (BN / WN + 4) * 4;
     const int S = a.kt * a.kh * a.kw * a.kpt + a.kpt2;
     const int slots = (MINW >= 4 && a.ring == 2) ? 2 : NSTAGE;
     const int ring_bytes = (S < slots ? S : slots) * (BN + BM) * 128;
@@ -435,11 +499,12 @@ static int launch(const ConvArgs& a, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<DT, BN, BM, WN, WM, KS, NSTAGE, MINW, DUAL>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE * (BN + BM) * 128);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           NSTAGE * (BN + BM) * 128 > patch_bytes ? NSTAGE * (BN + BM) * 128 : patch_bytes);
         if (e != hipSuccess) return set_error(AF_ERR_LAUNCH, "conv: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_igemm_kernel<DT, BN, BM, WN, WM, KS, NSTAGE, MINW, DUAL>), dim3((unsigned)blocks), dim3(512), lds, stream, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<DT, BN, BM, WN, WM, KS, NSTAGE, MINW, DUAL>), dim3((unsigned)blocks), dim3(WN * WM * KS * 64), lds, stream, a);
     AF_CHECK_LAUNCH("conv_igemm_kernel");
     return AF_OK;
 }
@@ -448,14 +513,23 @@ static int launch(const ConvArgs& a, hipStream_t stream) {
 // MFMA-bound: biggest tile.  Short-K layers (<= 3 K-steps) are HBM-bound streams of input, residual and
 // output: half-height tiles with a trimmed ring so several workgroups share a CU and overlap each
 // other's load / store phases.
-enum { VAR_128x256 = 0, VAR_64x256 = 1, VAR_128x128 = 2, VAR_64x128 = 3, VAR_C133 = 4, VAR_128x128_R2 = 5, VAR_COUNT = 6 };
+enum { VAR_128x256 = 0, VAR_64x256 = 1, VAR_128x128 = 2, VAR_64x128 = 3, VAR_C133 = 4, VAR_128x128_R2 = 5, VAR_256x256 = 6,
+       VAR_COUNT = 7 };
 static const char* const kVariantNames[] = {"conv_igemm<BN=128,BM=256>", "conv_igemm<BN=64,BM=256>",
                                             "conv_igemm<BN=128,BM=128>", "conv_igemm<BN=64,BM=128>",
-                                            "conv133_c64<weights in registers>", "conv_igemm<BN=128,BM=128>"};
+                                            "conv133_c64<weights in registers>", "conv_igemm<BN=128,BM=128>",
+                                            "conv_igemm<BN=256,BM=256>"};
 
-static int pick_variant(int cout, int cin, int taps, int dtype, int cin2 = 0) {
+static int pick_variant(int cout, int cin, int taps, int dtype, long long M, int cin2 = 0) {
     const int ksteps = (taps * cin + cin2) / (dtype == AF_F32 ? 32 : 64);
     const bool wide = cout % 128 == 0, short_k = ksteps <= 3;
+    if (cout % 256 == 0 && !cin2 && ksteps >= 9) {
+        // 256x256 tiles (128x64 per wave) move a third less L2 -> LDS traffic per MAC, which is what bounds the
+        // 128x256 tile; a layer is as slow as its last round of workgroups, so compare whole rounds on the 256 CUs
+        // (measured: one 256x256 tile takes 1.63x the time of a 128x256 tile)
+        const long long tm = (M + 255) / 256, big = tm * (cout / 256), v0 = tm * (cout / 128);
+        if (big >= 128 && (double)((big + 255) / 256) < 0.615 * (double)((v0 + 255) / 256) + 0.05) return VAR_256x256;
+    }
     if (wide && !short_k && ksteps <= 8 && cout >= 512) return VAR_128x128_R2;   // wide-output streams, 4..8 K-steps
     return wide ? (short_k ? VAR_128x128 : VAR_128x256) : (short_k ? VAR_64x128 : VAR_64x256);
 }
@@ -468,8 +542,8 @@ static int dispatch(ConvArgs& a, hipStream_t stream) {
     a.kpt2 = a.in2 ? (a.Cin2 + BK - 1) / BK : 0;
     a.Cin2P = a.kpt2 * BK;
     a.CoutP = (a.Cout + 63) / 64 * 64;
-    const int v = pick_variant(a.CoutP, a.CinP, a.kt * a.kh * a.kw, DT, a.in2 ? a.Cin2P : 0);
-    a.tiles_n = a.CoutP / ((v == VAR_128x256 || v == VAR_128x128 || v == VAR_128x128_R2) ? 128 : 64);
+    const int v = pick_variant(a.CoutP, a.CinP, a.kt * a.kh * a.kw, DT, a.M, a.in2 ? a.Cin2P : 0);
+    a.tiles_n = a.CoutP / (v == VAR_256x256 ? 256 : (v == VAR_128x256 || v == VAR_128x128 || v == VAR_128x128_R2) ? 128 : 64);
     a.ring = v == VAR_128x128_R2 ? 2 : 3;
     if (a.in2) {                                 // projection blocks (64-wide tiles: SlowFast's Fast pathway)
         switch (v) {
@@ -481,6 +555,7 @@ static int dispatch(ConvArgs& a, hipStream_t stream) {
         }
     }
     switch (v) {
+        case VAR_256x256: return launch<DT, 256, 256, 2, 4, 1, 2, false, 2>(a, stream);
         case VAR_128x256: return launch<DT, 128, 256, 2, 4, 1, 2, false>(a, stream);
         case VAR_64x256: return launch<DT, 64, 256, 1, 8, 1, 2, false>(a, stream);
         case VAR_128x128:
@@ -496,7 +571,7 @@ extern "C" int af_conv_variant(const af_conv_desc* d, const af_conv_desc* d2) {
     if (!d2 && af::conv133_applies(d, nullptr, 0)) return af::VAR_C133;
     const int bk = d->dtype == AF_F32 ? 32 : 64;
     return af::pick_variant((d->cout + 63) / 64 * 64, (d->cin + bk - 1) / bk * bk, d->kt * d->kh * d->kw, d->dtype,
-                            d2 ? (d2->cin + bk - 1) / bk * bk : 0);
+                            (long long)d->n * d->to * d->ho * d->wo, d2 ? (d2->cin + bk - 1) / bk * bk : 0);
 }
 
 extern "C" const char* af_conv_variant_name(int variant) {
@@ -526,6 +601,11 @@ static int conv_common(const af_conv_desc* d, const void* in, const void* w_pack
     AF_REQUIRE((long long)(d->cout + 63) * d->kt * d->kh * d->kw * (d->cin + bk) < (1LL << 31), "conv: weight too large");
     AF_REQUIRE(d->kt * d->kh * d->kw <= 31, "conv: at most 31 kernel taps (got %d)", d->kt * d->kh * d->kw);
     AF_REQUIRE((long long)d->kt * d->h * d->w * d->cin * dtype_size(d->dtype) < (1LL << 31), "conv: tap offset overflows");
+    // buffer addressing: a tile's rows are reached by 32-bit offsets from its first row, which needs input offsets
+    // that grow with the output position (padding at most half the kernel) and a tile that spans less than 2 GiB
+    AF_REQUIRE(2 * d->pt <= d->kt && 2 * d->ph <= d->kh && 2 * d->pw <= d->kw, "conv: padding larger than half the kernel");
+    AF_REQUIRE((256 / ((long long)to * ho * wo) + 3) * d->t * d->h * d->w * d->cin * dtype_size(d->dtype) < (1LL << 31),
+               "conv: one clip of input is too large for 32-bit tile offsets");
 
     if (!d2 && conv133_applies(d, residual, out_ld))
         return conv133_run(d, in, w_packed, scale, shift, out, (hipStream_t)stream);
@@ -549,6 +629,8 @@ static int conv_common(const af_conv_desc* d, const void* in, const void* w_pack
         AF_REQUIRE(d2->st > 0 && d2->sh > 0 && d2->sw > 0 && (d2->t - 1) / d2->st + 1 == to && (d2->h - 1) / d2->sh + 1 == ho &&
                        (d2->w - 1) / d2->sw + 1 == wo, "conv: second segment does not land on the same output positions");
         AF_REQUIRE(d2->cin > 0 && d2->cin % epc == 0, "conv: second segment cin=%d must be a multiple of %d", d2->cin, epc);
+        AF_REQUIRE((256 / ((long long)to * ho * wo) + 3) * d2->t * d2->h * d2->w * d2->cin * dtype_size(d->dtype) < (1LL << 31),
+                   "conv: one clip of the second input is too large for 32-bit tile offsets");
         a.in2 = (const char*)in2; a.w2 = (const char*)w2_packed;
         a.T2 = d2->t; a.H2 = d2->h; a.W2 = d2->w; a.Cin2 = d2->cin; a.st2 = d2->st; a.sh2 = d2->sh; a.sw2 = d2->sw;
     }

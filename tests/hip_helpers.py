@@ -54,6 +54,7 @@ def conv_bn_act(x_ndhwc, w_oidhw, scale, shift, stride, pad, relu, dtype, residu
     d.pt, d.ph, d.pw = pad
     d.to, d.ho, d.wo = [(a + 2 * p - k) // s + 1 for a, p, k, s in zip((t, h, w), pad, (kt, kh, kw), stride)]
     d.relu, d.dtype, d.tpool = int(relu), code, int(tpool)
+    conv_bn_act.last_variant = L.lib.af_conv_variant(C.byref(d), None)     # which kernel the library picks for this layer
     wsrc = w_oidhw.float().cuda().contiguous()
     nbytes = L.lib.af_packed_conv_weight_bytes(cout, cin, kt, kh, kw, code)
     packed = torch.empty(nbytes // (4 if dtype == "f32" else 2), dtype=TORCH_DT[dtype], device="cuda")

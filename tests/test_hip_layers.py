@@ -155,7 +155,11 @@ CONV_CASES = [
     ("sf_fast_16_1x3x3_s2", 16, 16, (1, 3, 3), (1, 2, 2), (0, 1, 1), (1, 4, 11, 12), True, False),
     ("sf_slow_320to128", 320, 128, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 2, 7, 8), True, False),
     ("sf_fuse_32to64_t8", 32, 64, (5, 1, 1), (8, 1, 1), (2, 0, 0), (1, 32, 3, 4), True, False),
+    # large enough for the 256x256 tile (4 waves, accumulators in AGPRs, 2-slot ring): full and ragged last tile
+    ("tile256_1x3x3_res", 64, 256, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 16, 56, 56), True, True),
+    ("tile256_ragged_m", 64, 256, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 16, 56, 55), False, False),
 ]
+EXPECT_VARIANT = {"tile256_1x3x3_res": 6, "tile256_ragged_m": 6}
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -181,6 +185,8 @@ def test_conv_vs_oracle(case, dtype):
         want = F.relu(want)
     got = hh.conv_bn_act(hh.to_ndhwc(x, dtype), sd["w.weight"], *hh.fold_bn(sd, "bn"), s, p, relu, dtype,
                          residual=None if res is None else hh.to_ndhwc(res, dtype))
+    if name in EXPECT_VARIANT:
+        assert hh.conv_bn_act.last_variant == EXPECT_VARIANT[name], hh.conv_bn_act.last_variant
     tol = {"f32": 2e-6, "f16": 1.5e-3, "bf16": 1.2e-2}[dtype]     # operands pre-rounded: only output rounding + fp32 accumulation remain
     got = hh.to_ncdhw(got).double()
     err = (got - want).abs().max().item()
