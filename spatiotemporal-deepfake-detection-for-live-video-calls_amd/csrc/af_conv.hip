@@ -514,11 +514,11 @@ static int launch(const ConvArgs& a, hipStream_t stream) {
 // output: half-height tiles with a trimmed ring so several workgroups share a CU and overlap each
 // other's load / store phases.
 enum { VAR_128x256 = 0, VAR_64x256 = 1, VAR_128x128 = 2, VAR_64x128 = 3, VAR_C133 = 4, VAR_128x128_R2 = 5, VAR_256x256 = 6,
-       VAR_COUNT = 7 };
+       VAR_128x512 = 7, VAR_COUNT = 8 };
 static const char* const kVariantNames[] = {"conv_igemm<BN=128,BM=256>", "conv_igemm<BN=64,BM=256>",
                                             "conv_igemm<BN=128,BM=128>", "conv_igemm<BN=64,BM=128>",
                                             "conv133_c64<weights in registers>", "conv_igemm<BN=128,BM=128>",
-                                            "conv_igemm<BN=256,BM=256>"};
+                                            "conv_igemm<BN=256,BM=256>", "conv_igemm<BN=128,BM=512>"};
 
 static int pick_variant(int cout, int cin, int taps, int dtype, long long M, int cin2 = 0) {
     const int ksteps = (taps * cin + cin2) / (dtype == AF_F32 ? 32 : 64);
@@ -529,6 +529,12 @@ static int pick_variant(int cout, int cin, int taps, int dtype, long long M, int
         // (measured: one 256x256 tile takes 1.63x the time of a 128x256 tile)
         const long long tm = (M + 255) / 256, big = tm * (cout / 256), v0 = tm * (cout / 128);
         if (big >= 128 && (double)((big + 255) / 256) < 0.615 * (double)((v0 + 255) / 256) + 0.05) return VAR_256x256;
+    }
+    if (cout == 128 && !cin2 && taps >= 9) {
+        // the same 128x64-per-wave layout turned on its side for 128-channel layers: 128x512 tiles (1x3x3 layers;
+        // the 3x1x1 / 1x1x1 ones stream their activations from HBM and measured no faster)
+        const long long big = (M + 511) / 512, v0 = (M + 255) / 256;
+        if (big >= 128 && (double)((big + 255) / 256) < 0.615 * (double)((v0 + 255) / 256) + 0.05) return VAR_128x512;
     }
     if (wide && !short_k && ksteps <= 8 && cout >= 512) return VAR_128x128_R2;   // wide-output streams, 4..8 K-steps
     return wide ? (short_k ? VAR_128x128 : VAR_128x256) : (short_k ? VAR_64x128 : VAR_64x256);
@@ -543,7 +549,7 @@ static int dispatch(ConvArgs& a, hipStream_t stream) {
     a.Cin2P = a.kpt2 * BK;
     a.CoutP = (a.Cout + 63) / 64 * 64;
     const int v = pick_variant(a.CoutP, a.CinP, a.kt * a.kh * a.kw, DT, a.M, a.in2 ? a.Cin2P : 0);
-    a.tiles_n = a.CoutP / (v == VAR_256x256 ? 256 : (v == VAR_128x256 || v == VAR_128x128 || v == VAR_128x128_R2) ? 128 : 64);
+    a.tiles_n = a.CoutP / (v == VAR_256x256 ? 256 : (v == VAR_128x256 || v == VAR_128x512 || v == VAR_128x128 || v == VAR_128x128_R2) ? 128 : 64);
     a.ring = v == VAR_128x128_R2 ? 2 : 3;
     if (a.in2) {                                 // projection blocks (64-wide tiles: SlowFast's Fast pathway)
         switch (v) {
@@ -556,6 +562,7 @@ static int dispatch(ConvArgs& a, hipStream_t stream) {
     }
     switch (v) {
         case VAR_256x256: return launch<DT, 256, 256, 2, 4, 1, 2, false, 2>(a, stream);
+        case VAR_128x512: return launch<DT, 128, 512, 2, 4, 1, 2, false, 2>(a, stream);
         case VAR_128x256: return launch<DT, 128, 256, 2, 4, 1, 2, false>(a, stream);
         case VAR_64x256: return launch<DT, 64, 256, 1, 8, 1, 2, false>(a, stream);
         case VAR_128x128:

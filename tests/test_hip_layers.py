@@ -158,8 +158,11 @@ CONV_CASES = [
     # large enough for the 256x256 tile (4 waves, accumulators in AGPRs, 2-slot ring): full and ragged last tile
     ("tile256_1x3x3_res", 64, 256, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 16, 56, 56), True, True),
     ("tile256_ragged_m", 64, 256, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 16, 56, 55), False, False),
+    # ... and for the 128x512 tile of 128-channel layers (its 2-slot ring is the whole 160 KB of LDS)
+    ("tile512_1x3x3_res", 128, 128, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 8, 96, 96), True, True),
+    ("tile512_ragged_m", 128, 128, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 8, 96, 95), False, False),
 ]
-EXPECT_VARIANT = {"tile256_1x3x3_res": 6, "tile256_ragged_m": 6}
+EXPECT_VARIANT = {"tile256_1x3x3_res": 6, "tile256_ragged_m": 6, "tile512_1x3x3_res": 7, "tile512_ragged_m": 7}
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
