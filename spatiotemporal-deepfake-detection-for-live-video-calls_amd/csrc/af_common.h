@@ -11,10 +11,39 @@ namespace af {
 
 int set_error(int code, const char* fmt, ...);
 
+// ---- LDS-DMA helpers shared by the convolution kernels
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// one 16-byte-per-lane LDS-DMA: LDS[lds_base + lane*16 .. +16) <- desc.base[voff + soff .. +16); a lane whose
+// voff is outside the descriptor's 2 GiB window (kOutOfRange) gets zeros - that is how padding taps, rows beyond M
+// and channel tails are filled.  hipcc does not count this load: every wait on it is an explicit s_waitcnt vmcnt(N).
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned kOutOfRange = 0x80000000u;
+__device__ __forceinline__ void blds16(unsigned voff, const i32x4& desc, int soff, unsigned lds_base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(desc), "s"(lds_base), "s"(soff) : "memory");
+}
+// raw buffer descriptor over [base, base + 2 GiB): stride 0, no swizzle, 32-bit data format
+__device__ __forceinline__ i32x4 make_desc(const char* base) {
+    const unsigned long long b = (unsigned long long)base;
+    i32x4 d;
+    d[0] = __builtin_amdgcn_readfirstlane((int)(b & 0xffffffffu));
+    d[1] = __builtin_amdgcn_readfirstlane((int)((b >> 32) & 0xffffu));
+    d[2] = (int)kOutOfRange;
+    d[3] = 0x00020000;
+    return d;
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
 // af_conv133.hip: register-resident-weights 1x3x3 64->64 kernel (s2 `b` convs), 16-bit dtypes
 bool conv133_applies(const af_conv_desc* d, const void* residual, int out_ld);
 int conv133_run(const af_conv_desc* d, const void* in, const void* w_packed, const float* scale, const float* shift,
                 void* out, hipStream_t stream);
+// af_conv311.hip: time-tiled 3x1x1 -> 64 channels kernel (s2 `a` convs): the three taps share one LDS image
+bool conv311_applies(const af_conv_desc* d, const void* residual, int out_ld);
+int conv311_run(const af_conv_desc* d, const void* in, const void* w_packed, const float* scale, const float* shift,
+                void* out, int out_ld, hipStream_t stream);
 
 #define AF_REQUIRE(cond, ...)                                    \
     do {                                                         \

@@ -25,8 +25,6 @@
 
 namespace af {
 
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
 struct ConvArgs {
     const char* in;
     const char* w;
@@ -50,29 +48,6 @@ struct ConvArgs {
     const char* w2;
     int T2, H2, W2, Cin2, Cin2P, st2, sh2, sw2, kpt2;
 };
-
-// one 16-byte-per-lane LDS-DMA: LDS[lds_base + lane*16 .. +16) <- desc.base[voff + soff .. +16); a lane whose
-// voff is outside the descriptor's 2 GiB window (kOutOfRange) gets zeros - that is how padding taps, rows beyond M
-// and channel tails are filled.  hipcc does not count this load: every wait on it is an explicit s_waitcnt vmcnt(N).
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-constexpr unsigned kOutOfRange = 0x80000000u;
-__device__ __forceinline__ void blds16(unsigned voff, const i32x4& desc, int soff, unsigned lds_base) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(desc), "s"(lds_base), "s"(soff) : "memory");
-}
-// raw buffer descriptor over [base, base + 2 GiB): stride 0, no swizzle, 32-bit data format
-__device__ __forceinline__ i32x4 make_desc(const char* base) {
-    const unsigned long long b = (unsigned long long)base;
-    i32x4 d;
-    d[0] = __builtin_amdgcn_readfirstlane((int)(b & 0xffffffffu));
-    d[1] = __builtin_amdgcn_readfirstlane((int)((b >> 32) & 0xffffu));
-    d[2] = (int)kOutOfRange;
-    d[3] = 0x00020000;
-    return d;
-}
-
-template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // NW = WN*WM*KS = 8 waves (512 threads); wave (wn, wm) owns a (BN/WN) x (BM/WM) sub-tile of 16x16
 // MFMA tiles.
@@ -514,11 +489,12 @@ static int launch(const ConvArgs& a, hipStream_t stream) {
 // output: half-height tiles with a trimmed ring so several workgroups share a CU and overlap each
 // other's load / store phases.
 enum { VAR_128x256 = 0, VAR_64x256 = 1, VAR_128x128 = 2, VAR_64x128 = 3, VAR_C133 = 4, VAR_128x128_R2 = 5, VAR_256x256 = 6,
-       VAR_128x512 = 7, VAR_COUNT = 8 };
+       VAR_128x512 = 7, VAR_C311 = 8, VAR_COUNT = 9 };
 static const char* const kVariantNames[] = {"conv_igemm<BN=128,BM=256>", "conv_igemm<BN=64,BM=256>",
                                             "conv_igemm<BN=128,BM=128>", "conv_igemm<BN=64,BM=128>",
                                             "conv133_c64<weights in registers>", "conv_igemm<BN=128,BM=128>",
-                                            "conv_igemm<BN=256,BM=256>", "conv_igemm<BN=128,BM=512>"};
+                                            "conv_igemm<BN=256,BM=256>", "conv_igemm<BN=128,BM=512>",
+                                            "conv311_c64<time-tiled, taps share one LDS image>"};
 
 static int pick_variant(int cout, int cin, int taps, int dtype, long long M, int cin2 = 0) {
     const int ksteps = (taps * cin + cin2) / (dtype == AF_F32 ? 32 : 64);
@@ -576,6 +552,7 @@ static int dispatch(ConvArgs& a, hipStream_t stream) {
 extern "C" int af_conv_variant(const af_conv_desc* d, const af_conv_desc* d2) {
     AF_REQUIRE(d && d->cout > 0 && d->cin > 0 && af::dtype_ok(d->dtype), "conv_variant: bad descriptor");
     if (!d2 && af::conv133_applies(d, nullptr, 0)) return af::VAR_C133;
+    if (!d2 && af::conv311_applies(d, nullptr, 0)) return af::VAR_C311;
     const int bk = d->dtype == AF_F32 ? 32 : 64;
     return af::pick_variant((d->cout + 63) / 64 * 64, (d->cin + bk - 1) / bk * bk, d->kt * d->kh * d->kw, d->dtype,
                             (long long)d->n * d->to * d->ho * d->wo, d2 ? (d2->cin + bk - 1) / bk * bk : 0);
@@ -616,6 +593,8 @@ static int conv_common(const af_conv_desc* d, const void* in, const void* w_pack
 
     if (!d2 && conv133_applies(d, residual, out_ld))
         return conv133_run(d, in, w_packed, scale, shift, out, (hipStream_t)stream);
+    if (!d2 && conv311_applies(d, residual, out_ld))
+        return conv311_run(d, in, w_packed, scale, shift, out, out_ld, (hipStream_t)stream);
 
     ConvArgs a;
     a.in = (const char*)in; a.w = (const char*)w_packed; a.scale = scale; a.shift = shift;

@@ -161,8 +161,14 @@ CONV_CASES = [
     # ... and for the 128x512 tile of 128-channel layers (its 2-slot ring is the whole 160 KB of LDS)
     ("tile512_1x3x3_res", 128, 128, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 8, 96, 96), True, True),
     ("tile512_ragged_m", 128, 128, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 8, 96, 95), False, False),
+    # time-tiled 3x1x1 -> 64 kernel (T = 32: 8 positions per tile, T = 16: 16), ragged last spatial chunk, several tiles
+    # per workgroup only at bench sizes - here every workgroup gets one or two
+    ("t311_64to64_T32", 64, 64, (3, 1, 1), (1, 1, 1), (1, 0, 0), (2, 32, 7, 9), True, False),
+    ("t311_256to64_T16", 256, 64, (3, 1, 1), (1, 1, 1), (1, 0, 0), (1, 16, 10, 10), True, False),
+    ("t311_256to64_T32_many", 256, 64, (3, 1, 1), (1, 1, 1), (1, 0, 0), (3, 32, 28, 28), False, False),
 ]
-EXPECT_VARIANT = {"tile256_1x3x3_res": 6, "tile256_ragged_m": 6, "tile512_1x3x3_res": 7, "tile512_ragged_m": 7}
+EXPECT_VARIANT = {"tile256_1x3x3_res": 6, "tile256_ragged_m": 6, "tile512_1x3x3_res": 7, "tile512_ragged_m": 7,
+                  "t311_64to64_T32": 8, "t311_256to64_T16": 8, "t311_256to64_T32_many": 8}
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
