@@ -1,27 +1,27 @@
-// 3x1x1 / stride 1 / pad (1,0,0) convolution into 64 channels + BN + ReLU: the temporal `a` conv of the s2
-// bottlenecks (reference altfreezing/slowfast/models/resnet_helper.py:267-281; 64->64 in res0, 256->64 after it).
+// 3x1x1 / stride 1 / pad (1,0,0) convolution into 64 or 128 channels + BN + ReLU: the temporal `a` conv of the
+// s2 / s3 bottlenecks (reference altfreezing/slowfast/models/resnet_helper.py:267-281).
 //
 // The generic implicit GEMM brings every activation row into LDS once PER TAP.  For a temporal kernel the three
 // taps of an output position are the SAME spatial position in frames t-1, t, t+1 - rows that other outputs of the
 // same workgroup need anyway if the tile is cut along time.  This kernel therefore tiles M as
-//     tile = (clip n, P consecutive spatial positions, ALL T frames),   P = 256 / T   (8 for T = 32, 16 for T = 16)
+//     tile = (clip n, P consecutive spatial positions, ALL T frames),   P = BM / T   (8 or 16)
 // and keeps, per 64-channel K slab, ONE activation image in LDS: (T + 2) x P rows (row = (t + 1) * P + p; the two
 // extra frames are the zero padding, fetched as out-of-range lanes).  Tap dt of output row r is LDS row r + dt * P:
 // a constant row shift that is a multiple of 8, so the XOR swizzle (chunk ^ (row & 7)) is unchanged and every B
 // fragment stays one conflict-free ds_read_b128.  L2 -> LDS traffic for activations drops 3x (the layer was bound
 // by exactly that), and what remains is close to the HBM stream of the layer.
 //
-// A stage = one K slab: 3 x 64 weight rows (tap-major) + the activation image = 58-60 KB; 2-slot ring.  The
+// A stage = one K slab: 3 x BN weight rows (tap-major) + the activation image = 58-68 KB; 2-slot ring.  The
 // workgroup is persistent: the stage stream runs on across tile boundaries, so the first slab of the next tile
-// is in flight while the epilogue of this one (BN + ReLU through a per-wave fp32 patch, 16-byte row stores) runs.
-// 8 waves, each 64 channels x 32 rows of the tile.
+// is in flight while the epilogue of this one (BN + ReLU, transposed through a per-wave patch in the output type,
+// 16-byte row stores) runs.  8 waves, each 64 channels x 32 rows: BN = 64 -> 256-row tiles, BN = 128 -> 128-row tiles.
 #include "af_common.h"
 
 namespace af {
 
 struct C311Args {
     const char* in;
-    const char* w;       // packed [64][3][CinP]
+    const char* w;       // packed [BN][3][CinP]
     const float* scale;
     const float* shift;
     char* out;
@@ -31,15 +31,16 @@ struct C311Args {
     int relu, out_ld;
 };
 
-template <int DT>
-__global__ __launch_bounds__(512, 2) void conv311_c64_kernel(const C311Args a) {
+template <int DT, int BN>
+__global__ __launch_bounds__(512, 2) void conv311_kernel(const C311Args a) {
     typedef Elem<DT> E;
+    typedef typename E::type OT;
     constexpr int EPC = E::EPC, ES = 16 / EPC;
-    constexpr int BN = 64, BM = 256, TN = 4, TM = 2;
+    constexpr int WN = BN / 64, BM = 256 / WN, TN = 4, TM = 2;
     constexpr int WROWS = 3 * BN;                      // weight rows per stage: (dt, channel)
-    constexpr int WPIECES = WROWS / 8 / 8;             // = 3 DMA pieces per wave
-    constexpr int XPW = 5;                             // activation pieces per wave (covers up to 320 rows)
-    constexpr int PROW = BN + 4;                       // patch row stride (floats)
+    constexpr int WPIECES = WROWS / 8 / 8;             // DMA pieces per wave: 3 or 6
+    constexpr int XPW = (BM + 2 * 16) / 8 / 8 + 1;     // activation pieces per wave (rows: BM + 2 P, P <= 16)
+    constexpr int PROW = 64 + EPC;                     // patch row stride (elements; keeps rows 16-byte aligned)
 
     extern __shared__ uint4 smem[];
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
@@ -49,7 +50,8 @@ __global__ __launch_bounds__(512, 2) void conv311_c64_kernel(const C311Args a) {
     const int P = a.P, XR = BM + 2 * P;                // activation rows per stage
     const int XP = XR >> 3;                            // activation pieces per stage
     const int stage_bytes = (WROWS + XR) * 128;
-    float* patch = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + 2 * stage_bytes) + wave * (16 * PROW);
+    OT* patch = reinterpret_cast<OT*>(reinterpret_cast<char*>(smem) + 2 * stage_bytes) + wave * (16 * PROW);
+    const int wn = wave % WN, wm = wave / WN;          // channel half (BN = 128), 32-row group
 
     // ---- producer state: per-lane offsets that never change
     const int drow = lane >> 3, chunk = (lane & 7) ^ drow;       // row inside a piece; source chunk (row & 7 == drow)
@@ -58,7 +60,7 @@ __global__ __launch_bounds__(512, 2) void conv311_c64_kernel(const C311Args a) {
     unsigned woff[WPIECES];
 #pragma unroll
     for (int i = 0; i < WPIECES; ++i) {
-        const int row = (wave + 8 * i) * 8 + drow, dt = row >> 6, ch = row & 63;
+        const int row = (wave + 8 * i) * 8 + drow, dt = row / BN, ch = row % BN;
         woff[i] = (unsigned)((ch * Kw + (long long)dt * a.kpt * 8 * EPC) * ES + chunk * 16);
     }
     // activation row (t, p) of the tile: offset from the tile origin (clip n, frame 0, position hw0)
@@ -100,8 +102,8 @@ __global__ __launch_bounds__(512, 2) void conv311_c64_kernel(const C311Args a) {
     f32x4 sc[TN], sf[TN];
 #pragma unroll
     for (int i = 0; i < TN; ++i) {
-        sc[i] = *reinterpret_cast<const f32x4*>(a.scale + i * 16 + fg * 4);
-        sf[i] = *reinterpret_cast<const f32x4*>(a.shift + i * 16 + fg * 4);
+        sc[i] = *reinterpret_cast<const f32x4*>(a.scale + wn * 64 + i * 16 + fg * 4);
+        sf[i] = *reinterpret_cast<const f32x4*>(a.shift + wn * 64 + i * 16 + fg * 4);
     }
 
     if (total > 0) issue_stage(0);
@@ -111,8 +113,8 @@ __global__ __launch_bounds__(512, 2) void conv311_c64_kernel(const C311Args a) {
         wait_vmcnt<0>();                                         // stage q (the only one in flight) has landed ...
         __builtin_amdgcn_s_barrier();                            // ... for everyone, and slot (q+1)&1 is no longer read
         if (q + 1 < total) issue_stage(slot ^ 1);
-        const uint4* ws = smem + slot * (stage_bytes / 16) + frow * 8;
-        const uint4* xs = smem + slot * (stage_bytes / 16) + WROWS * 8 + (wave * 32 + frow) * 8;
+        const uint4* ws = smem + slot * (stage_bytes / 16) + (wn * 64 + frow) * 8;
+        const uint4* xs = smem + slot * (stage_bytes / 16) + WROWS * 8 + (wm * 32 + frow) * 8;
 #pragma unroll
         for (int dt = 0; dt < 3; ++dt)
 #pragma unroll
@@ -120,7 +122,7 @@ __global__ __launch_bounds__(512, 2) void conv311_c64_kernel(const C311Args a) {
                 const int c = (kk * 4 + fg) ^ (frow & 7);
                 uint4 af[TN], bf[TM];
 #pragma unroll
-                for (int i = 0; i < TN; ++i) af[i] = ws[(dt * 64 + i * 16) * 8 + c];
+                for (int i = 0; i < TN; ++i) af[i] = ws[(dt * BN + i * 16) * 8 + c];
 #pragma unroll
                 for (int j = 0; j < TM; ++j) bf[j] = xs[(dt * P + j * 16) * 8 + c];
 #pragma unroll
@@ -130,36 +132,29 @@ __global__ __launch_bounds__(512, 2) void conv311_c64_kernel(const C311Args a) {
             }
         if (++c_kc < a.kpt) continue;
 
-        // ---- tile finished: BN + ReLU, transpose through the wave's patch, 16-byte row stores
+        // ---- tile finished: BN + ReLU + the one rounding, transpose through the wave's patch, 16-byte row stores
         const int n = c_tile / a.chunks, hw0 = (c_tile % a.chunks) * P;
-        constexpr int LPR = BN / EPC, RPI = 64 / LPR;            // lanes per output row; rows per wave-instruction
+        constexpr int LPR = 64 / EPC, RPI = 64 / LPR;            // lanes per output row; rows per wave-instruction
         const int rr = lane / LPR, cc = (lane % LPR) * EPC;
 #pragma unroll
         for (int j = 0; j < TM; ++j) {
 #pragma unroll
             for (int i = 0; i < TN; ++i) {
-                *reinterpret_cast<f32x4*>(patch + frow * PROW + i * 16 + fg * 4) = acc[i][j] * sc[i] + sf[i];
+                f32x4 v = acc[i][j] * sc[i] + sf[i];
+                if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                Vec4<DT>::store(reinterpret_cast<char*>(patch + frow * PROW + i * 16 + fg * 4), v);
                 acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int it = 0; it < 16 / RPI; ++it) {
                 const int row = it * RPI + rr;
-                const int r = wave * 32 + j * 16 + row;          // tile row = t * P + p
+                const int r = wm * 32 + j * 16 + row;            // tile row = t * P + p
                 const int t = r / P, p = r % P;
-                float v[EPC];
-#pragma unroll
-                for (int e = 0; e < EPC; e += 4) {
-                    const f32x4 x = *reinterpret_cast<const f32x4*>(patch + row * PROW + cc + e);
-                    v[e] = x[0]; v[e + 1] = x[1]; v[e + 2] = x[2]; v[e + 3] = x[3];
-                }
+                const u32x4 o = *reinterpret_cast<const u32x4*>(patch + row * PROW + cc);
                 if (hw0 + p < a.HW) {
-                    uint4 o;
-                    typename E::type* oe = reinterpret_cast<typename E::type*>(&o);
-#pragma unroll
-                    for (int e = 0; e < EPC; ++e) oe[e] = E::from_f32(a.relu ? fmaxf(v[e], 0.f) : v[e]);
                     const long long pos = ((long long)n * a.T + t) * a.HW + hw0 + p;
-                    __builtin_nontemporal_store(__builtin_bit_cast(u32x4, o), reinterpret_cast<u32x4*>(a.out + (pos * a.out_ld + cc) * ES));
+                    __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(a.out + (pos * a.out_ld + wn * 64 + cc) * ES));
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -168,32 +163,42 @@ __global__ __launch_bounds__(512, 2) void conv311_c64_kernel(const C311Args a) {
     }
 }
 
-template <int DT>
+template <int DT, int BN>
 static int launch311(const C311Args& a, int blocks, hipStream_t stream) {
-    const int lds = 2 * (3 * 64 + 256 + 2 * a.P) * 128 + 8 * 16 * (64 + 4) * 4;
+    constexpr int BM = 256 / (BN / 64), EPC = Elem<DT>::EPC;
+    const int lds = 2 * (3 * BN + BM + 2 * a.P) * 128 + 8 * 16 * (64 + EPC) * (16 / EPC);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv311_c64_kernel<DT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv311_kernel<DT, BN>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return set_error(AF_ERR_LAUNCH, "conv311: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv311_c64_kernel<DT>), dim3(blocks), dim3(512), lds, stream, a);
-    AF_CHECK_LAUNCH("conv311_c64_kernel");
+    hipLaunchKernelGGL((conv311_kernel<DT, BN>), dim3(blocks), dim3(512), lds, stream, a);
+    AF_CHECK_LAUNCH("conv311_kernel");
     return AF_OK;
+}
+
+// tile height for a layer, 0 if the layer does not take the time-tiled path
+static int conv311_tile_rows(const af_conv_desc* d) {
+    if (d->tpool) return 0;
+    if (d->kt != 3 || d->kh != 1 || d->kw != 1 || d->st != 1 || d->sh != 1 || d->sw != 1) return 0;
+    if (d->pt != 1 || d->ph != 0 || d->pw != 0) return 0;
+    const int bke = d->dtype == AF_F32 ? 32 : 64;
+    if (d->cin % bke != 0) return 0;
+    int bm = 0;
+    if (d->cout == 64 && (d->t == 16 || d->t == 32)) bm = 256;                        // P = 16 or 8
+    else if (d->cout == 128 && d->t == 16 && d->dtype != AF_F32) bm = 128;            // P = 8 (fp32: ring + patch exceed LDS)
+    if (!bm) return 0;
+    if ((long long)d->t * d->h * d->w * d->cin * dtype_size(d->dtype) >= (1LL << 31)) return 0;
+    const int p = bm / d->t;
+    if ((long long)d->n * ((d->h * d->w + p - 1) / p) >= (1LL << 31)) return 0;
+    return bm;
 }
 
 // true iff this layer takes the time-tiled path (also used by af_conv_variant)
 bool conv311_applies(const af_conv_desc* d, const void* residual, int out_ld) {
-    if (residual || d->tpool) return false;
-    if (d->kt != 3 || d->kh != 1 || d->kw != 1 || d->st != 1 || d->sh != 1 || d->sw != 1) return false;
-    if (d->pt != 1 || d->ph != 0 || d->pw != 0 || d->cout != 64) return false;
-    const int bke = d->dtype == AF_F32 ? 32 : 64;
-    if (d->cin % bke != 0) return false;
-    if (d->t != 16 && d->t != 32) return false;                      // P = 256 / T in {16, 8}: the 2-slot ring fits LDS
-    if ((long long)d->t * d->h * d->w * d->cin * dtype_size(d->dtype) >= (1LL << 31)) return false;
-    if ((long long)d->n * ((d->h * d->w + 256 / d->t - 1) / (256 / d->t)) >= (1LL << 31)) return false;
-    return true;
+    return !residual && conv311_tile_rows(d) != 0;
 }
 
 int conv311_run(const af_conv_desc* d, const void* in, const void* w_packed, const float* scale, const float* shift,
@@ -201,7 +206,7 @@ int conv311_run(const af_conv_desc* d, const void* in, const void* w_packed, con
     C311Args a;
     a.in = (const char*)in; a.w = (const char*)w_packed; a.scale = scale; a.shift = shift; a.out = (char*)out;
     a.T = d->t; a.HW = d->h * d->w; a.Cin = d->cin; a.kpt = d->cin / (d->dtype == AF_F32 ? 32 : 64);
-    a.P = 256 / d->t; a.chunks = (a.HW + a.P - 1) / a.P; a.tiles = d->n * a.chunks;
+    a.P = conv311_tile_rows(d) / d->t; a.chunks = (a.HW + a.P - 1) / a.P; a.tiles = d->n * a.chunks;
     a.relu = d->relu; a.out_ld = out_ld;
     static int cus = 0;                                  // persistent grid: one workgroup per CU
     if (cus == 0) {
@@ -211,10 +216,11 @@ int conv311_run(const af_conv_desc* d, const void* in, const void* w_packed, con
         cus = n;
     }
     const int blocks = a.tiles < cus ? a.tiles : cus;
+    if (d->cout == 128) return d->dtype == AF_BF16 ? launch311<AF_BF16, 128>(a, blocks, stream) : launch311<AF_F16, 128>(a, blocks, stream);
     switch (d->dtype) {
-        case AF_F32: return launch311<AF_F32>(a, blocks, stream);
-        case AF_BF16: return launch311<AF_BF16>(a, blocks, stream);
-        default: return launch311<AF_F16>(a, blocks, stream);
+        case AF_F32: return launch311<AF_F32, 64>(a, blocks, stream);
+        case AF_BF16: return launch311<AF_BF16, 64>(a, blocks, stream);
+        default: return launch311<AF_F16, 64>(a, blocks, stream);
     }
 }
 

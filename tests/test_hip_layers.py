@@ -166,9 +166,11 @@ CONV_CASES = [
     ("t311_64to64_T32", 64, 64, (3, 1, 1), (1, 1, 1), (1, 0, 0), (2, 32, 7, 9), True, False),
     ("t311_256to64_T16", 256, 64, (3, 1, 1), (1, 1, 1), (1, 0, 0), (1, 16, 10, 10), True, False),
     ("t311_256to64_T32_many", 256, 64, (3, 1, 1), (1, 1, 1), (1, 0, 0), (3, 32, 28, 28), False, False),
+    ("t311_256to128_T16", 256, 128, (3, 1, 1), (1, 1, 1), (1, 0, 0), (2, 16, 9, 9), True, False),   # 128-row tiles; fp32 -> generic
 ]
 EXPECT_VARIANT = {"tile256_1x3x3_res": 6, "tile256_ragged_m": 6, "tile512_1x3x3_res": 7, "tile512_ragged_m": 7,
-                  "t311_64to64_T32": 8, "t311_256to64_T16": 8, "t311_256to64_T32_many": 8}
+                  "t311_64to64_T32": 8, "t311_256to64_T16": 8, "t311_256to64_T32_many": 8,
+                  "t311_256to128_T16": {"f32": 0, "f16": 8, "bf16": 8}}
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -195,7 +197,8 @@ def test_conv_vs_oracle(case, dtype):
     got = hh.conv_bn_act(hh.to_ndhwc(x, dtype), sd["w.weight"], *hh.fold_bn(sd, "bn"), s, p, relu, dtype,
                          residual=None if res is None else hh.to_ndhwc(res, dtype))
     if name in EXPECT_VARIANT:
-        assert hh.conv_bn_act.last_variant == EXPECT_VARIANT[name], hh.conv_bn_act.last_variant
+        want_variant = EXPECT_VARIANT[name][dtype] if isinstance(EXPECT_VARIANT[name], dict) else EXPECT_VARIANT[name]
+        assert hh.conv_bn_act.last_variant == want_variant, hh.conv_bn_act.last_variant
     tol = {"f32": 2e-6, "f16": 1.5e-3, "bf16": 1.2e-2}[dtype]     # operands pre-rounded: only output rounding + fp32 accumulation remain
     got = hh.to_ncdhw(got).double()
     err = (got - want).abs().max().item()
