@@ -8,7 +8,7 @@
 //     36 MFMA A-fragments (9 taps x 2 k-halves x 2 channel tiles = 144 VGPRs) for the life of the workgroup;
 //     the A operand never touches LDS;
 //   * a workgroup walks a contiguous run of image strips (R = 4 output rows); each strip's input patch
-//     ((R+2) rows, zero halo columns included) is brought in ONCE by LDS-DMA, double-buffered under the MFMAs
+//     ((R+2) rows, zero halo columns included) is brought in ONCE by LDS-DMA (buffer loads; out-of-range lanes = zeros), double-buffered under the MFMAs
 //     of the previous strip, and all 9 taps read it: with the rows stored at a padded pitch WP = W + 2 a tap
 //     (dh,dw) is the constant row offset dh*WP + dw, so every B fragment is a plain swizzled ds_read_b128;
 //   * positions are the padded strip (R x WP, two halo columns per row computed and discarded: 3.4 % waste).
@@ -17,7 +17,6 @@
 
 namespace af {
 
-__device__ uint4 g_zero_page_c133[8];         // 128 bytes of zeros: source of halo / out-of-image pixels
 
 struct C133Args {
     const char* in;
@@ -30,11 +29,6 @@ struct C133Args {
     int rows_alloc;      // LDS rows per patch buffer (multiple of 8)
 };
 
-__device__ __forceinline__ void glds16_c133(const void* gsrc, unsigned lds_base) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_base) : "memory");
-}
 
 template <int DT, int R>
 __global__ __launch_bounds__(512, 2) void conv133_c64_kernel(const C133Args a) {
@@ -66,27 +60,34 @@ __global__ __launch_bounds__(512, 2) void conv133_c64_kernel(const C133Args a) {
                 const int ch = nh * 32 + i * 16 + frow;
                 wreg[tap][kk][i] = *reinterpret_cast<const uint4*>(a.w + ((ch * 9 + tap) * 64 + kk * 32 + fg * 8) * 2);
             }
-    f32x4 sc[2], sf[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        sc[i] = *reinterpret_cast<const f32x4*>(a.scale + nh * 32 + i * 16 + fg * 4);
-        sf[i] = *reinterpret_cast<const f32x4*>(a.shift + nh * 32 + i * 16 + fg * 4);
-    }
+    // BN scale / shift wait in LDS (the weights take 144 VGPRs; a spill would put scratch loads - and their
+    // vmcnt(0), which also waits for the patch DMA in flight - into the strip loop)
+    float* bn_lds = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + 2 * buf_bytes) + 8 * 16 * PROW;
+    if (tid < 64) { bn_lds[tid] = a.scale[tid]; bn_lds[64 + tid] = a.shift[tid]; }
 
-    const char* zero = reinterpret_cast<const char*>(g_zero_page_c133);
+    // ---- patch producer.  LDS row j of a patch <-> padded pixel q = j - 1 : (r, c') = (q / WP, q % WP), input pixel
+    // (h0 + r - 1, c' - 1).  The (r, c') split and the source offset of every (piece, lane) are the same for every
+    // strip, so they are worked out once into an LDS table (entry = r << 24 | byte offset from pixel (h0 - 1, 0);
+    // all ones = halo column / beyond the patch); per strip a piece costs one table read, the row test and the DMA.
+    // Out-of-image lanes get an offset outside the buffer descriptor's range and the hardware writes zeros.
+    unsigned* dma_tab = reinterpret_cast<unsigned*>(bn_lds + 128);
     const int dma_row = lane >> 3, dma_chunk = (lane & 7) ^ dma_row;      // LDS row inside a piece; source chunk
-    // patch LDS row j <-> padded pixel q = j - 1 : (r, c') = (q / WP, q % WP), input pixel (h0 + r - 1, c' - 1)
+    for (int g = wave; g < NP; g += 8) {
+        const int q = g * 8 + dma_row - 1;
+        const int r = q / WP, c = q - r * WP;
+        const bool ok = q >= 0 && r < R + 2 && c >= 1 && c <= a.W;
+        dma_tab[g * 64 + lane] = ok ? ((unsigned)r << 24) | (unsigned)((r * a.W + (c - 1)) * 128 + dma_chunk * 16) : 0xffffffffu;
+    }
+    __syncthreads();                                   // table + BN parameters visible to every wave
     auto issue_patch = [&](int strip, int buf) {
         const int frame = strip / a.strips_per_frame;
         const int h0 = (strip - frame * a.strips_per_frame) * R;
-        const char* fbase = a.in + (long long)frame * a.H * a.W * 128 + dma_chunk * 16;
+        // origin = pixel (h0 - 1, 0) of the frame (one row above the image for the first strip: those lanes are masked)
+        const i32x4 desc = make_desc(a.in + ((long long)frame * a.H + h0 - 1) * a.W * 128);
         for (int g = wave; g < NP; g += 8) {
-            const int q = g * 8 + dma_row - 1;
-            const int r = q / WP, c = q - r * WP;
-            const int hi = h0 + r - 1;
-            const bool ok = q >= 0 && r < R + 2 && c >= 1 && c <= a.W && (unsigned)hi < (unsigned)a.H;
-            const char* src = ok ? fbase + ((long long)hi * a.W + (c - 1)) * 128 : zero;
-            glds16_c133(src, __builtin_amdgcn_readfirstlane(lds0 + buf * buf_bytes + g * 1024));   // provably wave-uniform
+            const unsigned e = dma_tab[g * 64 + lane];
+            const bool ok = e != 0xffffffffu && (unsigned)(h0 - 1 + (int)(e >> 24)) < (unsigned)a.H;
+            blds16(ok ? (e & 0xffffffu) : kOutOfRange, desc, 0, __builtin_amdgcn_readfirstlane(lds0 + buf * buf_bytes + g * 1024));
         }
     };
 
@@ -107,6 +108,8 @@ __global__ __launch_bounds__(512, 2) void conv133_c64_kernel(const C133Args a) {
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int k = 0; k < MT; ++k) acc[i][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // (a software-pipelined version of this loop - fragment reads one step ahead, no branches - measured slower:
+        // with the weights in 144 VGPRs it spills, and the two waves of a SIMD already cover each other's LDS reads)
 #pragma unroll
         for (int dh = 0; dh < 3; ++dh)
 #pragma unroll
@@ -130,6 +133,12 @@ __global__ __launch_bounds__(512, 2) void conv133_c64_kernel(const C133Args a) {
         const int frame = s / a.strips_per_frame;
         const int h0 = (s - frame * a.strips_per_frame) * R;
         const int prow = lane >> 2, pcc = (lane & 3) * 8;
+        f32x4 sc[2], sf[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            sc[i] = *reinterpret_cast<const f32x4*>(bn_lds + nh * 32 + i * 16 + fg * 4);
+            sf[i] = *reinterpret_cast<const f32x4*>(bn_lds + 64 + nh * 32 + i * 16 + fg * 4);
+        }
 #pragma unroll
         for (int k = 0; k < MT; ++k) {
             const int t = mg + 4 * k;
@@ -175,7 +184,7 @@ static int launch_c133(C133Args& a, hipStream_t stream) {
     a.strips_per_frame = (a.H + R - 1) / R;
     a.total_strips = a.frames * a.strips_per_frame;
     a.rows_alloc = (((R + 2) * WP + 2 + 16) + 7) & ~7;
-    const int lds = 2 * a.rows_alloc * 128 + 8 * 16 * 36 * 4;
+    const int lds = 2 * a.rows_alloc * 128 + 8 * 16 * 36 * 4 + 128 * 4 + (a.rows_alloc / 8) * 64 * 4;
     const int grid = a.total_strips < g_num_cus ? a.total_strips : g_num_cus;
     static bool attr_set = false;
     if (!attr_set) {
