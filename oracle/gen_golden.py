@@ -331,6 +331,74 @@ def gen_slowfast():
     np.savez_compressed(os.path.join(GOLD, "f5_slowfast_stages.npz"), **f5)
 
 
+def gen_ftcn():
+    """F6: the reference's FTCN-TT plugin (`classifier_type: i3d_temporal_var_fix_dropout_tt_cfg`, setting/ftcn_tt.yaml).
+    Run in its OWN process (`python -m oracle.gen_golden --ftcn`): the reference config is a process-wide singleton.
+    Two harness patches, neither touching arithmetic: `timm.models.layers.trunc_normal_` (absent package; only seeds the
+    random init that the fixture overwrites) and the plugin's module-level list of nn.Conv3d constructor parameters,
+    from which this torch's `device` / `dtype` entries are dropped (they are not attributes of a built module, so the
+    unmodified plugin raises AttributeError on torch >= 1.9)."""
+    import importlib
+    ref_import._install_shims()
+    for n in ("timm", "timm.models"):
+        ref_import._mod(n)
+    ref_import._mod("timm.models.layers").trunc_normal_ = torch.nn.init.trunc_normal_
+    cfg, _ = ref_import.import_reference("ftcn_tt.yaml")
+    mod = importlib.import_module("model.classifier." + cfg.classifier_type)
+    mod.parameters = [p for p in mod.parameters if p not in ("device", "dtype")]
+    clf = mod.Classifier().eval()
+    net = clf.network
+    spec = arch.ftcn_tt_spec()
+    lay = [(k, list(v.shape), str(v.dtype).replace("torch.", "")) for k, v in net.state_dict().items()]
+    mine = [(k, list(sh), d) for k, sh, d in arch.state_dict_layout(spec)]
+    assert mine == lay, "product FTCN-TT table disagrees with the reference state_dict layout"
+    sd = synth.synthetic_state_dict(spec, seed=WEIGHT_SEED)
+    net.load_state_dict(sd)
+
+    stage_out, hooks = {}, []
+    for name in ("s1", "s2", "s3", "s4"):
+        def mk(n):
+            def hook(m, inp, out):
+                stage_out[n] = out[0].detach().clone()
+            return hook
+        hooks.append(getattr(net.resnet, name).register_forward_hook(mk(name)))
+    hooks.append(net.resnet.head.time_T.register_forward_hook(
+        lambda m, inp, out: stage_out.__setitem__("tokens", inp[0].detach().clone())))
+    entries, f6 = [], {}
+    for ci, (kind, seed, index) in enumerate([("uniform", CLIP_SEED, 0), ("smooth", CLIP_SEED, 0)]):
+        u8 = synth.synthetic_clips_u8(index + 1, seed=seed, kind=kind)[index:index + 1]
+        x = synth.normalize_like_callers(u8)
+        with torch.no_grad():
+            y32 = clf(x)["final_output"]
+        if ci == 0:
+            for n, t in stage_out.items():
+                flat = t.flatten()
+                idx = _sample_idx(flat.numel())
+                f6["%s_shape" % n] = np.array(t.shape, dtype=np.int64)
+                f6["%s_absmean" % n] = np.array([flat.double().abs().mean().item()])
+                f6["%s_idx" % n] = idx.numpy()
+                f6["%s_val" % n] = flat[idx].numpy()
+            # known-answer vector for the transformer head alone: its real input and output
+            f6["head_tokens"] = stage_out["tokens"].numpy()
+            f6["head_logit"] = y32.numpy()
+        net.double()
+        with torch.no_grad():
+            y64 = net(x.double())["final_output"]
+        net.float()
+        entries.append({"kind": kind, "seed": seed, "index": index, "clip_sha256": synth.tensor_sha256(u8),
+                        "logit_f32": float(y32[0, 0]), "logit_f64": float(y64[0, 0])})
+        print("F6 ftcn_tt clip", kind, "logit f32 %.9g f64 %.12g" % (y32[0, 0].item(), y64[0, 0].item()))
+    for h in hooks:
+        h.remove()
+    with open(os.path.join(GOLD, "f6_ftcn.json"), "w") as f:
+        json.dump({"source": "reference model/classifier/i3d_temporal_var_fix_dropout_tt_cfg.py Classifier() with "
+                             "setting/ftcn_tt.yaml (stop_point 5, depth 1, patch_type time), PyTorch CPU, weights W(seed) "
+                             "in its state_dict layout",
+                   "num_keys": len(lay), "num_params": int(sum(p.numel() for p in net.parameters())),
+                   "weights_seed": WEIGHT_SEED, "weights_sha256": synth.state_dict_sha256(sd), "clips": entries}, f, indent=1)
+    np.savez_compressed(os.path.join(GOLD, "f6_ftcn_stages.npz"), **f6)
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.manual_seed(0)
@@ -344,4 +412,10 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if "--ftcn" in sys.argv:
+        os.makedirs(GOLD, exist_ok=True)
+        torch.manual_seed(0)
+        torch.set_num_threads(8)
+        gen_ftcn()
+    else:
+        main()

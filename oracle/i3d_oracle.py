@@ -109,6 +109,86 @@ def forward(sd, x, num_frames=32, crop=224, dtype=torch.float32, return_stages=F
     return logits
 
 
+# ---- FTCN-TT (altfreezing/model/classifier/i3d_temporal_var_fix_dropout_tt_cfg.py, time_transformer.py) ----------
+def _conv_bn_pool_act(x, w, sd, bn_prefix, pad, pool2, relu):
+    """conv (stride 1) -> BN -> [MaxPool3d((1,2,2)), where `temporal_only_conv` (:207-288) removed a stride 2 and wrapped
+    the BN into nn.Sequential(bn, pool) - hence the `.0` in the key] -> [ReLU]."""
+    y = F.conv3d(x, w.to(x.dtype), None, stride=1, padding=pad)
+    y = _bn(y, sd, bn_prefix + (".0" if pool2 else ""))
+    if pool2:
+        y = F.max_pool3d(y, kernel_size=(1, 2, 2))
+    return F.relu(y) if relu else y
+
+
+def ftcn_stem(x, sd, p="resnet.s1.pathway0_stem"):
+    w = sd[p + ".conv.weight"]                      # (64, 3, 5, 1, 1)
+    x = _conv_bn_pool_act(x, w, sd, p + ".bn", (w.shape[2] // 2, 0, 0), True, True)
+    return F.max_pool3d(x, kernel_size=(1, 3, 3), stride=(1, 2, 2), padding=(0, 1, 1))   # stem_helper.py:171,178
+
+
+def ftcn_block(x, sd, p):
+    pool2 = (p + ".branch2.b_bn.0.weight") in sd    # block 0 of s3 / s4
+    wa = sd[p + ".branch2.a.weight"]
+    y = _conv_bn_pool_act(x, wa, sd, p + ".branch2.a_bn", (wa.shape[2] // 2, 0, 0), False, True)
+    y = _conv_bn_pool_act(y, sd[p + ".branch2.b.weight"], sd, p + ".branch2.b_bn", (0, 0, 0), pool2, True)
+    y = _conv_bn_pool_act(y, sd[p + ".branch2.c.weight"], sd, p + ".branch2.c_bn", (0, 0, 0), False, False)
+    if (p + ".branch1.weight") in sd:
+        sc = _conv_bn_pool_act(x, sd[p + ".branch1.weight"], sd, p + ".branch1_bn", (0, 0, 0), pool2, False)
+    else:
+        sc = x
+    return F.relu(sc + y)
+
+
+def ftcn_stage(x, sd, stage):
+    for i in range(_num_blocks(sd, stage)):
+        x = ftcn_block(x, sd, "resnet.s%d.pathway0_res%d" % (stage, i))
+    return x
+
+
+def layer_norm(x, sd, p):
+    return F.layer_norm(x, (x.shape[-1],), sd[p + ".weight"].to(x.dtype), sd[p + ".bias"].to(x.dtype), 1e-5)
+
+
+def time_transformer(tokens, sd, p="resnet.head.time_T", heads=16):
+    """TimeTransformer.forward (time_transformer.py:268-281), depth 1: class token + position embedding, pre-norm
+    attention (:36-71, scale dim_head^-0.5, no qkv bias) and pre-norm GELU MLP (:23-34), both residual (:8-13),
+    then LayerNorm + Linear on the class token.  tokens: (B, N, D)."""
+    b, n, d = tokens.shape
+    x = torch.cat([sd[p + ".cls_token"].to(tokens.dtype).expand(b, 1, d), tokens], dim=1)
+    x = x + sd[p + ".pos_embedding"].to(tokens.dtype)[:, :n + 1]
+    l0, l1 = p + ".transformer.layers.0.0.fn", p + ".transformer.layers.0.1.fn"
+    h = layer_norm(x, sd, l0 + ".norm")
+    qkv = F.linear(h, sd[l0 + ".fn.to_qkv.weight"].to(h.dtype))
+    q, k, v = [t.reshape(b, n + 1, heads, -1).transpose(1, 2) for t in qkv.chunk(3, dim=-1)]
+    att = (q @ k.transpose(-1, -2) * (q.shape[-1] ** -0.5)).softmax(dim=-1)
+    o = (att @ v).transpose(1, 2).reshape(b, n + 1, -1)
+    x = x + F.linear(o, sd[l0 + ".fn.to_out.0.weight"].to(h.dtype), sd[l0 + ".fn.to_out.0.bias"].to(h.dtype))
+    h = layer_norm(x, sd, l1 + ".norm")
+    h = F.gelu(F.linear(h, sd[l1 + ".fn.net.0.weight"].to(h.dtype), sd[l1 + ".fn.net.0.bias"].to(h.dtype)))
+    x = x + F.linear(h, sd[l1 + ".fn.net.3.weight"].to(h.dtype), sd[l1 + ".fn.net.3.bias"].to(h.dtype))
+    c = layer_norm(x[:, 0], sd, p + ".mlp_head.0")
+    return F.linear(c, sd[p + ".mlp_head.1.weight"].to(c.dtype), sd[p + ".mlp_head.1.bias"].to(c.dtype))
+
+
+def ftcn_forward(sd, x, dtype=torch.float32, return_stages=False):
+    """x: (B,3,T,H,W) normalised clip -> (B,1) logits of the FTCN-TT plugin (stop_point 5, patch_type 'time')."""
+    x = x.to(dtype)
+    stages = OrderedDict()
+    with torch.no_grad():
+        x = ftcn_stem(x, sd); stages["s1"] = x
+        x = ftcn_stage(x, sd, 2); stages["s2"] = x
+        x = F.max_pool3d(x, kernel_size=(2, 1, 1), stride=(2, 1, 1))
+        x = ftcn_stage(x, sd, 3); stages["s3"] = x
+        x = ftcn_stage(x, sd, 4); stages["s4"] = x
+        tok = F.avg_pool3d(x, kernel_size=(1, x.shape[3], x.shape[4]))          # TransformerHead 'time' (:133-135)
+        tok = tok.reshape(x.shape[0], x.shape[1], x.shape[2]).permute(0, 2, 1)  # (B, T/2, C)   (:186-188)
+        stages["tokens"] = tok
+        logits = time_transformer(tok, sd)
+    if return_stages:
+        return logits, stages
+    return logits
+
+
 # ---- two-pathway SlowFast (altfreezing/slowfast/models/video_model_builder.py:86-143, 146-387) ----------------
 
 def _stage_pathway(x, sd, stage, pathway):

@@ -38,6 +38,12 @@ class ConvSpec:
     pad: Tuple[int, int, int]
     relu: bool                     # ReLU directly after the BN
     final_bn: bool = False         # `transform_final_bn` marker (resnet_helper.py:309)
+    pool_after_bn: Optional["PoolSpec"] = None   # FTCN: MaxPool3d between the BN and the ReLU; the BN then lives in an
+                                                 # nn.Sequential, i.e. under `<bn>.0` in the state_dict
+
+    @property
+    def bn_key(self):
+        return self.bn + ".0" if self.pool_after_bn is not None else self.bn
 
     @property
     def weight_shape(self):
@@ -245,17 +251,107 @@ def slowfast_r50_spec(num_frames: int = 32, crop: int = 224, alpha: int = 8, bet
         head_in=c_slow + c_fast, num_classes=1)
 
 
+@dataclass(frozen=True)
+class FtcnTTSpec:
+    """The repo's second classifier plugin, FTCN-TT (reference altfreezing/model/classifier/
+    i3d_temporal_var_fix_dropout_tt_cfg.py:207-359 with setting/ftcn_tt.yaml): the I3D-R50 trunk with EVERY spatial
+    kernel shrunk to 1x1 (`temporal_only_conv`, :207-288: a stride-2 conv becomes stride 1 + MaxPool3d((1,2,2)) placed
+    after its BN, before the ReLU), s5 dropped (`stop_point: 5`), and a one-layer pre-norm transformer over the
+    T/2 = 16 per-frame tokens (AvgPool3d((1,14,14)) of s4) + a class token as the head (:127-197,
+    time_transformer.py:219-276: dim 1024, 16 heads x 64, MLP 2048, GELU)."""
+    num_frames: int
+    crop: int
+    stem: ConvSpec
+    stem_pool: PoolSpec
+    stages: Tuple[StageSpec, ...]
+    pool_after_s2: PoolSpec
+    tokens: int                    # per-frame tokens (the class token is extra)
+    token_pool: Tuple[int, int, int]
+    dim: int
+    heads: int
+    dim_head: int
+    mlp_dim: int
+    num_classes: int
+    head: str = "resnet.head.time_T"
+
+    def convs(self) -> List[ConvSpec]:
+        out = [self.stem]
+        for st in self.stages:
+            for blk in st.blocks:
+                if blk.branch1 is not None:
+                    out.append(blk.branch1)
+                out += [blk.a, blk.b, blk.c]
+        return out
+
+    def head_layout(self):
+        h, d, inner = self.head, self.dim, self.heads * self.dim_head
+        l0, l1 = h + ".transformer.layers.0.0.fn", h + ".transformer.layers.0.1.fn"
+        return [(h + ".pos_embedding", (1, self.tokens + 1, d), "float32"), (h + ".cls_token", (1, 1, d), "float32"),
+                (l0 + ".norm.weight", (d,), "float32"), (l0 + ".norm.bias", (d,), "float32"),
+                (l0 + ".fn.to_qkv.weight", (3 * inner, d), "float32"),
+                (l0 + ".fn.to_out.0.weight", (d, inner), "float32"), (l0 + ".fn.to_out.0.bias", (d,), "float32"),
+                (l1 + ".norm.weight", (d,), "float32"), (l1 + ".norm.bias", (d,), "float32"),
+                (l1 + ".fn.net.0.weight", (self.mlp_dim, d), "float32"), (l1 + ".fn.net.0.bias", (self.mlp_dim,), "float32"),
+                (l1 + ".fn.net.3.weight", (d, self.mlp_dim), "float32"), (l1 + ".fn.net.3.bias", (d,), "float32"),
+                (h + ".mlp_head.0.weight", (d,), "float32"), (h + ".mlp_head.0.bias", (d,), "float32"),
+                (h + ".mlp_head.1.weight", (self.num_classes, d), "float32"),
+                (h + ".mlp_head.1.bias", (self.num_classes,), "float32")]
+
+    def linear_prefixes(self):
+        h = self.head
+        return [h + ".transformer.layers.0.0.fn.fn.to_qkv", h + ".transformer.layers.0.0.fn.fn.to_out.0",
+                h + ".transformer.layers.0.1.fn.fn.net.0", h + ".transformer.layers.0.1.fn.fn.net.3", h + ".mlp_head.1"]
+
+
+def ftcn_tt_spec(num_frames: int = 32, crop: int = 224) -> FtcnTTSpec:
+    pool2 = PoolSpec((1, 2, 2), (1, 2, 2), (0, 0, 0))
+    kt = _I3D_TEMPORAL_BASIS[0][0]
+    stem = ConvSpec("resnet.s1.pathway0_stem.conv", "resnet.s1.pathway0_stem.bn", 3, _WIDTH, (kt, 1, 1), (1, 1, 1),
+                    (kt // 2, 0, 0), relu=True, pool_after_bn=pool2)
+    stages = []
+    dim_in = _WIDTH
+    for si, depth in enumerate(_STAGE_DEPTH_R50[:3]):                 # s2..s4; s5 is an nn.Identity (stop_point 5)
+        sname = "resnet.s%d" % (si + 2)
+        inner, dim_out = _WIDTH * (2 ** si), _WIDTH * (2 ** si) * 4
+        tks = _block_temporal_kernels(_I3D_TEMPORAL_BASIS[si + 1], depth, depth)
+        blocks = []
+        for bi in range(depth):
+            bname = "%s.pathway0_res%d" % (sname, bi)
+            cin = dim_in if bi == 0 else dim_out
+            down = pool2 if (si > 0 and bi == 0) else None             # where the reference net strides by 2
+            tk = tks[bi]
+            branch1 = None
+            if cin != dim_out or down is not None:
+                branch1 = ConvSpec(bname + ".branch1", bname + ".branch1_bn", cin, dim_out, (1, 1, 1), (1, 1, 1),
+                                   (0, 0, 0), relu=False, pool_after_bn=down)
+            a = ConvSpec(bname + ".branch2.a", bname + ".branch2.a_bn", cin, inner, (tk, 1, 1), (1, 1, 1),
+                         (tk // 2, 0, 0), relu=True)
+            b = ConvSpec(bname + ".branch2.b", bname + ".branch2.b_bn", inner, inner, (1, 1, 1), (1, 1, 1), (0, 0, 0),
+                         relu=True, pool_after_bn=down)
+            c = ConvSpec(bname + ".branch2.c", bname + ".branch2.c_bn", inner, dim_out, (1, 1, 1), (1, 1, 1),
+                         (0, 0, 0), relu=False, final_bn=True)
+            blocks.append(BlockSpec(bname, branch1, a, b, c))
+        stages.append(StageSpec(sname, tuple(blocks)))
+        dim_in = dim_out
+    return FtcnTTSpec(num_frames=num_frames, crop=crop, stem=stem, stem_pool=PoolSpec((1, 3, 3), (1, 2, 2), (0, 1, 1)),
+                      stages=tuple(stages), pool_after_s2=PoolSpec((2, 1, 1), (2, 1, 1), (0, 0, 0)),
+                      tokens=num_frames // 2, token_pool=(1, crop // 16, crop // 16), dim=dim_in, heads=16,
+                      dim_head=64, mlp_dim=2048, num_classes=1)
+
+
 def state_dict_layout(spec):
     """[(key, shape, dtype_name)] in the reference's ``network.state_dict()`` order
     (320 keys for the i3d 32x224 config; 662 keys for SlowFast-R50)."""
     out = []
     for cv in spec.convs():
         out.append((cv.conv + ".weight", cv.weight_shape, "float32"))
-        out.append((cv.bn + ".weight", (cv.cout,), "float32"))
-        out.append((cv.bn + ".bias", (cv.cout,), "float32"))
-        out.append((cv.bn + ".running_mean", (cv.cout,), "float32"))
-        out.append((cv.bn + ".running_var", (cv.cout,), "float32"))
-        out.append((cv.bn + ".num_batches_tracked", (), "int64"))
+        out.append((cv.bn_key + ".weight", (cv.cout,), "float32"))
+        out.append((cv.bn_key + ".bias", (cv.cout,), "float32"))
+        out.append((cv.bn_key + ".running_mean", (cv.cout,), "float32"))
+        out.append((cv.bn_key + ".running_var", (cv.cout,), "float32"))
+        out.append((cv.bn_key + ".num_batches_tracked", (), "int64"))
+    if isinstance(spec, FtcnTTSpec):
+        return out + spec.head_layout()
     out.append((spec.head + ".weight", (spec.num_classes, spec.head_in), "float32"))
     out.append((spec.head + ".bias", (spec.num_classes,), "float32"))
     return out

@@ -41,7 +41,10 @@ def fill_layout(layout, seed: int, final_bn=(), linear=()) -> "OrderedDict[str, 
             fan_out = shape[0] * shape[2] * shape[3] * shape[4]
             t = torch.randn(shape, generator=g) * math.sqrt(2.0 / fan_out)
         elif prefix in linear:
-            t = torch.randn(shape, generator=g) * 0.05
+            # transformer-head linears: the reference's own trunc_normal std (time_transformer.py:262-266)
+            t = torch.randn(shape, generator=g) * (0.02 if ".transformer." in key else 0.05)
+        elif leaf in ("pos_embedding", "cls_token"):           # transformer head parameters: randn like the reference
+            t = torch.randn(shape, generator=g)
         elif leaf == "weight":                                 # BN gamma
             if prefix in final_bn:
                 t = torch.rand(shape, generator=g) * 0.4
@@ -62,8 +65,9 @@ def fill_layout(layout, seed: int, final_bn=(), linear=()) -> "OrderedDict[str, 
 def synthetic_state_dict(spec: NetSpec = None, seed: int = 0) -> "OrderedDict[str, torch.Tensor]":
     """W(seed): fp32 CPU tensors keyed/ordered like the reference state_dict."""
     spec = spec or i3d_r50_spec()
+    linear = spec.linear_prefixes() if hasattr(spec, "linear_prefixes") else [spec.head]
     return fill_layout(state_dict_layout(spec), seed,
-                       final_bn=[cv.bn for cv in spec.convs() if cv.final_bn], linear=[spec.head])
+                       final_bn=[cv.bn_key for cv in spec.convs() if cv.final_bn], linear=linear)
 
 
 def synthetic_tensor(shape, seed: int, scale: float = 1.0) -> torch.Tensor:

@@ -113,6 +113,29 @@ def test_slowfast_logits_and_stages():
                     np.testing.assert_allclose(got, st["%s_%s_val" % (name, tag)], rtol=1e-4, atol=1e-5)
 
 
+def test_ftcn_tt_logits_stages_and_head():
+    """oracle.ftcn_forward against the reference's FTCN-TT plugin (tests/golden/f6_ftcn*)."""
+    g = load_json("f6_ftcn.json")
+    st = load_npz("f6_ftcn_stages.npz")
+    spec = arch.ftcn_tt_spec()
+    assert g["num_keys"] == 275 == len(arch.state_dict_layout(spec)) and g["num_params"] == 14765889
+    sd = synth.synthetic_state_dict(spec, seed=g["weights_seed"])
+    assert synth.state_dict_sha256(sd) == g["weights_sha256"]
+    # the transformer head on its own: the reference's real token matrix -> its logit
+    got = oracle.time_transformer(torch.from_numpy(st["head_tokens"]), sd)
+    np.testing.assert_allclose(got.numpy(), st["head_logit"], rtol=0, atol=2e-6)
+    c = g["clips"][0]
+    u8 = synth.synthetic_clips_u8(c["index"] + 1, seed=c["seed"], kind=c["kind"])[c["index"]:c["index"] + 1]
+    assert synth.tensor_sha256(u8) == c["clip_sha256"]
+    logits, stages = oracle.ftcn_forward(sd, oracle.normalize(u8), return_stages=True)
+    assert logits.shape == (1, 1) and abs(float(logits[0, 0]) - c["logit_f32"]) <= 1e-5
+    for name in ("s1", "s2", "s3", "s4", "tokens"):
+        t = stages[name]
+        assert list(t.shape) == list(st["%s_shape" % name]), name
+        got = t.flatten()[torch.from_numpy(st["%s_idx" % name])].numpy()
+        np.testing.assert_allclose(got, st["%s_val" % name], rtol=1e-4, atol=1e-5)
+
+
 def test_checkpoint_unwrap_rules():
     base = {"resnet.a": torch.ones(1)}
     assert list(oracle.strip_checkpoint({"state_dict": {"module.resnet.a": 1}})) == ["resnet.a"]
