@@ -169,10 +169,36 @@ int af_avgpool(const af_pool_desc* d, const void* in, float* pooled, int pooled_
 int af_linear(const float* x, const float* w, const float* b, int rows, int in_features, int out_features,
               float* y, void* stream);
 
+/* ---- FTCN-TT plugin (reference model/classifier/i3d_temporal_var_fix_dropout_tt_cfg.py, time_transformer.py) ---- */
+
+/* Temporal stem: Conv3d(3->64,[kt,1,1],stride 1,pad [kt/2,0,0]) + BN + MaxPool3d((1,2,2)) + ReLU - what
+ * `temporal_only_conv` (:207-288) makes of ResNetBasicStem's conv / bn (stem_helper.py:156-178); d describes the conv
+ * with to/ho/wo = t, h/2, w/2 (the pool is fused).  stem_in: af_pack_input_* buffer; out: NDHWC [n][t][h/2][w/2][64].
+ * The stem's own MaxPool3d([1,3,3],[1,2,2],[0,1,1]) follows as af_maxpool3d. */
+int af_pack_tstem_weight(const float* w_oidhw, int cout, int kt, int dtype, void* out, void* stream);
+long long af_packed_tstem_weight_bytes(int dtype);
+int af_tstem_conv_bn_pool_relu(const af_conv_desc* d, const void* stem_in, const void* w_packed, const float* scale,
+                               const float* shift, void* out, void* stream);
+
+/* TimeTransformer head (time_transformer.py:219-281), fp32.  The Linear layers are af_conv3d_bn_act over the token
+ * rows (1x1x1, AF_F32, scale = ones, shift = bias, residual = the skip connection).
+ * af_tokens_assemble: out[b][0] = cls + pos[0], out[b][1+t] = pooled[b][t] + pos[1+t]   (:270-273)
+ * af_layernorm: nn.LayerNorm(dim) over `rows` rows (PreNorm :15-21; mlp_head :259), row strides in elements
+ * af_attention: softmax(q k^T / sqrt(dim_head)) v per (clip, head), qkv rows = [q | k | v] (Attention.forward :52-71)
+ * af_gelu: nn.GELU() (erf form) in place (FeedForward :27) */
+int af_tokens_assemble(const float* pooled, const float* cls_token, const float* pos_embedding, int clips, int n_tok,
+                       int dim, float* out, void* stream);
+int af_layernorm(const float* x, long long x_row_stride, const float* gamma, const float* beta, int rows, int dim,
+                 float eps, float* y, long long y_row_stride, void* stream);
+int af_attention(const float* qkv, int clips, int n_tok, int heads, int dim_head, float* out, void* stream);
+int af_gelu(float* x, long long n, void* stream);
+
 /* ---- whole-forward op list ------------------------------------------------------------ */
 
 enum af_op_kind { AF_OP_STEM = 0, AF_OP_CONV = 1, AF_OP_MAXPOOL = 2, AF_OP_HEAD = 3,
-                  AF_OP_PACK_F32 = 4, AF_OP_PACK_U8 = 5, AF_OP_CONV_DUAL = 6, AF_OP_STEM_POOL = 7, AF_OP_AVGPOOL = 8, AF_OP_LINEAR = 9 };
+                  AF_OP_PACK_F32 = 4, AF_OP_PACK_U8 = 5, AF_OP_CONV_DUAL = 6, AF_OP_STEM_POOL = 7, AF_OP_AVGPOOL = 8, AF_OP_LINEAR = 9,
+                  /* FTCN-TT: in/weight/scale/shift/out as commented in af_run_ops' switch (csrc/af_api.hip) */
+                  AF_OP_TSTEM = 10, AF_OP_TOKENS = 11, AF_OP_LAYERNORM = 12, AF_OP_ATTENTION = 13, AF_OP_GELU = 14 };
 
 typedef struct af_op {
     int32_t kind;                    /* af_op_kind */

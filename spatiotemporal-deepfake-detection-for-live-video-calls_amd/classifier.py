@@ -26,7 +26,7 @@ from typing import Dict, Optional, Tuple
 import torch
 from torch import nn
 
-from .arch import ConvSpec, NetSpec, i3d_r50_spec, slowfast_r50_spec
+from .arch import ConvSpec, NetSpec, ftcn_tt_spec, i3d_r50_spec, slowfast_r50_spec
 
 logger = logging.getLogger("af_mi355x")
 
@@ -73,7 +73,8 @@ def _init_like_reference(root: nn.Module, fc_std: float = 0.01, zero_init_final_
             m.bias.data.zero_()
         elif isinstance(m, nn.Linear):
             m.weight.data.normal_(mean=0.0, std=fc_std)
-            m.bias.data.zero_()
+            if m.bias is not None:
+                m.bias.data.zero_()
 
 
 class _HipNetwork(nn.Module):
@@ -88,12 +89,18 @@ class _HipNetwork(nn.Module):
         self.resnet = _Node()
         for cv in self.spec.convs():
             _attach(self, cv.conv, _conv_module(cv))
-            _attach(self, cv.bn, _bn_module(cv))
-        _attach(self, "resnet.head.dropout", nn.Dropout(0.5))
-        _attach(self, self.spec.head, nn.Linear(self.spec.head_in, self.spec.num_classes, bias=True))
+            _attach(self, cv.bn_key, _bn_module(cv))
+        self._build_head()
         _init_like_reference(self)
         self._packed: Dict[str, Tuple[tuple, object]] = {}      # dtype -> (signature, PackedWeights)
         self._engines: Dict[tuple, object] = {}                 # (dtype, batch, dims) -> Engine
+
+    def _build_head(self):
+        _attach(self, "resnet.head.dropout", nn.Dropout(0.5))
+        _attach(self, self.spec.head, nn.Linear(self.spec.head_in, self.spec.num_classes, bias=True))
+
+    def _head_linear(self) -> nn.Linear:
+        return self.resnet.head.projection
 
     # -- weight / engine caches ---------------------------------------------------------------------
     def _signature(self):
@@ -137,11 +144,13 @@ class _HipNetwork(nn.Module):
         return images if images.dtype == torch.float32 else images.float()
 
     def _finish(self, eng, logits, pooled, B):
-        proj = self.resnet.head.projection
+        proj = self._head_linear()
         if proj._forward_hooks or proj._forward_pre_hooks:
             # somebody (feature.py:105-114) listens on the head Linear: feed it the pooled feature in the
             # reference's (N,T',H',W',C) layout so the hook sees the same input/output as upstream
             feat = pooled.view((B,) + tuple(eng.head_dims) + (pooled.shape[-1],))
+            if not hasattr(self.resnet.head, "projection"):          # FTCN-TT: mlp_head's Linear sees (B, dim)
+                feat = pooled.view(B, pooled.shape[-1])
             return proj(feat.clone()).reshape(B, -1)
         return logits.clone().view(B, -1)
 
@@ -207,6 +216,56 @@ class SlowFast8x8(_HipNetwork):
         with torch.cuda.device(fast.device):
             eng = self._engine(self._select_dtype(), B, (T, H, W), fast.device)
             logits, pooled = eng.run_f32(*xs)
+            pred = self._finish(eng, logits, pooled, B)
+        return {"final_output": pred}
+
+
+class _TokenParams(_Node):
+    """pos_embedding / cls_token of the reference's TimeTransformer (time_transformer.py:243-244)."""
+
+    def __init__(self, tokens: int, dim: int):
+        super().__init__()
+        self.pos_embedding = nn.Parameter(torch.randn(1, tokens + 1, dim))
+        self.cls_token = nn.Parameter(torch.randn(1, 1, dim))
+
+
+class FtcnTT8x8(_HipNetwork):
+    """Network module of the reference's second plugin, FTCN-TT (``classifier_type: i3d_temporal_var_fix_dropout_tt_cfg``
+    with ``setting/ftcn_tt.yaml``; altfreezing/model/classifier/i3d_temporal_var_fix_dropout_tt_cfg.py:290-359):
+    I3D-R50 trunk with every spatial kernel shrunk to 1x1 (strides replaced by 2x2 max-pools after the BN), s5
+    dropped, and a one-layer TimeTransformer over 16 per-frame tokens + class token as the head.  Same parameter
+    names as the reference module (the BNs followed by a pool live under ``<bn>.0``), same forward contract."""
+
+    def __init__(self, clip_size: int = 32, imsize: int = 224, precision: str = "auto", crop_size: int = 224) -> None:
+        super().__init__(ftcn_tt_spec(num_frames=clip_size, crop=crop_size), precision)
+        self.clip_size, self.imsize = clip_size, imsize
+
+    def _build_head(self):
+        sp = self.spec
+        h, inner = sp.head, sp.heads * sp.dim_head
+        _attach(self, h, _TokenParams(sp.tokens, sp.dim))
+        l0, l1 = h + ".transformer.layers.0.0.fn", h + ".transformer.layers.0.1.fn"
+        _attach(self, l0 + ".norm", nn.LayerNorm(sp.dim))
+        _attach(self, l0 + ".fn.to_qkv", nn.Linear(sp.dim, 3 * inner, bias=False))
+        _attach(self, l0 + ".fn.to_out.0", nn.Linear(inner, sp.dim))
+        _attach(self, l1 + ".norm", nn.LayerNorm(sp.dim))
+        _attach(self, l1 + ".fn.net.0", nn.Linear(sp.dim, sp.mlp_dim))
+        _attach(self, l1 + ".fn.net.3", nn.Linear(sp.mlp_dim, sp.dim))
+        _attach(self, h + ".mlp_head.0", nn.LayerNorm(sp.dim))
+        _attach(self, h + ".mlp_head.1", nn.Linear(sp.dim, sp.num_classes))
+
+    def _head_linear(self) -> nn.Linear:
+        return getattr(self.resnet.head.time_T.mlp_head, "1")
+
+    def forward(self, images, noise=None, has_mask=None, freeze_backbone=False, return_feature_maps=False):
+        assert not freeze_backbone
+        x = self._check_input(images)
+        B, _, T, H, W = x.shape
+        if B == 0:
+            return {"final_output": x.new_zeros((0, self.spec.num_classes))}
+        with torch.cuda.device(x.device):
+            eng = self._engine(self._select_dtype(), B, (T, H, W), x.device)
+            logits, pooled = eng.run_f32(x)
             pred = self._finish(eng, logits, pooled, B)
         return {"final_output": pred}
 
@@ -314,3 +373,14 @@ class Classifier(nn.Module):
             logger.error(traceback.format_exc())
             raise
         return True, loaded_epoch
+
+
+class FtcnTTClassifier(Classifier):
+    """``classifier_type: i3d_temporal_var_fix_dropout_tt_cfg`` (setting/ftcn_tt.yaml:60): same ModelBase surface,
+    FTCN-TT network."""
+
+    name = "i3d_temporal_var_fix_dropout_tt_cfg"
+
+    @property
+    def module_to_build(self):
+        return FtcnTT8x8

@@ -43,6 +43,18 @@ static int run_one(const af_op& op, hipStream_t s) {
         case AF_OP_PACK_U8:
             return af_pack_input_u8((const uint8_t*)op.in, op.conv.n, op.conv.t, op.conv.h, op.conv.w, op.mean, op.std_,
                                     op.conv.dtype, op.out, s);
+        case AF_OP_TSTEM:
+            return af_tstem_conv_bn_pool_relu(&op.conv, op.in, op.weight, op.scale, op.shift, op.out, s);
+        case AF_OP_TOKENS:       /* in = pooled, weight = cls token, scale = position embedding; pool.n = clips, pool.t = tokens, pool.c = dim */
+            return af_tokens_assemble((const float*)op.in, (const float*)op.weight, op.scale, op.pool.n, op.pool.t, op.pool.c,
+                                      (float*)op.out, s);
+        case AF_OP_LAYERNORM:    /* in = x, scale = gamma, shift = beta; pool.n = rows, pool.c = dim, pool.h / pool.w = x / y row strides */
+            return af_layernorm((const float*)op.in, op.pool.h, op.scale, op.shift, op.pool.n, op.pool.c, 1e-5f, (float*)op.out,
+                                op.pool.w, s);
+        case AF_OP_ATTENTION:    /* in = qkv; pool.n = clips, pool.t = tokens, pool.h = heads, pool.w = dim_head */
+            return af_attention((const float*)op.in, op.pool.n, op.pool.t, op.pool.h, op.pool.w, (float*)op.out, s);
+        case AF_OP_GELU:         /* out = x (in place); pool.n * pool.c elements */
+            return af_gelu((float*)op.out, (long long)op.pool.n * op.pool.c, s);
         default:
             return set_error(AF_ERR_ARG, "run_ops: unknown op kind %d", op.kind);
     }

@@ -1,0 +1,292 @@
+// Kernels that only the FTCN-TT plugin needs (reference altfreezing/model/classifier/
+// i3d_temporal_var_fix_dropout_tt_cfg.py + time_transformer.py); its trunk otherwise runs on the I3D kernels
+// (all of its convolutions are Tx1x1 / 1x1x1).
+//
+//   * temporal stem: Conv3d(3->64, [kt,1,1], stride 1, pad [kt/2,0,0]) + BN + MaxPool3d((1,2,2)) + ReLU in one pass
+//     (`temporal_only_conv` :207-288 turns the 5x7x7/stride-2 stem into this; the stem's own 1x3x3/stride-2
+//     max-pool follows as a separate af_maxpool3d).  K = kt taps x 4 padded channels <= 32: one MFMA K-block.
+//   * the transformer head (time_transformer.py:8-83, 219-281) on 17 tokens x 1024 per clip, in fp32 throughout:
+//     token assembly (class token + position embedding), LayerNorm, softmax attention, exact GELU.  The four
+//     Linear layers run on the convolution kernel (fp32 MFMA, 1x1x1 over the token rows).
+#include "af_common.h"
+
+namespace af {
+
+// ------------------------------------------------------------------------------------------------------
+// temporal stem
+struct TStemArgs {
+    const char* in;      // packed clip [N][T + 2*PAD_T][H + 2*PAD_H][W + PAD_W_TOTAL][4] (af_pack_input_*)
+    const char* w;       // packed A fragments [KB][4 tiles][64 lanes][16 B]
+    const float* scale;
+    const float* shift;
+    char* out;           // [N][T][H/2][W/2][64]
+    int T, Hp, Wp, Tp;   // frames; padded input dims
+    int H, W, Ho, Wo;    // conv image; pooled image
+    int tiles_w;         // ceil(Wo / 4)
+    long long tiles;     // N * T * Ho * tiles_w
+    int t_off;           // first padded frame of tap 0 for output frame 0 (PAD_T - kt/2)
+    int kt;
+};
+
+// A wave owns tiles of 2 x 8 conv positions = 1 x 4 pooled pixels; lane = (fg = k-group, frow = position: row
+// frow >> 3, column frow & 7).  16-bit: one K-block of 32 = 8 tap slots x 4 channels, lane group fg holds taps
+// 2fg, 2fg+1.  fp32: K-blocks of 16 = 4 tap slots, lane group fg holds tap 4*kb + fg.
+template <int DT>
+__global__ __launch_bounds__(256) void tstem_kernel(const TStemArgs a) {
+    typedef Elem<DT> E;
+    constexpr int EPC = E::EPC, ES = 16 / EPC;
+    constexpr int TPC = EPC / 4;                    // taps per 16-byte chunk
+    constexpr int KB = DT == AF_F32 ? 2 : 1;        // K-blocks (kt <= 5 taps + padding)
+    constexpr int PIXB = 4 * ES;                    // bytes per padded pixel
+    const int lane = threadIdx.x & 63, frow = lane & 15, fg = lane >> 4;
+    const long long wave0 = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long long nwaves = (long long)gridDim.x * (blockDim.x >> 6);
+
+    uint4 wf[KB][4];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wf[kb][i] = reinterpret_cast<const uint4*>(a.w)[(kb * 4 + i) * 64 + lane];
+    f32x4 sc[4], sf[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        sc[i] = *reinterpret_cast<const f32x4*>(a.scale + i * 16 + fg * 4);
+        sf[i] = *reinterpret_cast<const f32x4*>(a.shift + i * 16 + fg * 4);
+    }
+    const long long row_b = (long long)a.Wp * PIXB, plane_b = row_b * a.Hp;
+    const int r = frow >> 3, c = frow & 7;
+
+    for (long long tile = wave0; tile < a.tiles; tile += nwaves) {
+        const int tw = (int)(tile % a.tiles_w); long long q = tile / a.tiles_w;
+        const int ph = (int)(q % a.Ho); q /= a.Ho;
+        const int t = (int)(q % a.T); const long long n = q / a.T;
+        int w = tw * 8 + c; if (w > a.W - 1) w = a.W - 1;               // ragged last tile: clamped, never stored
+        const int h = 2 * ph + r;
+        const char* px = a.in + ((n * a.Tp + t + a.t_off) * plane_b) + (long long)(h + AF_STEM_PAD_H) * row_b +
+                         (long long)(w + AF_STEM_PAD_W_LEFT) * PIXB;
+        f32x4 acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            // this lane's chunk: TPC consecutive taps starting at tap0; taps >= kt have zero weights and are not read
+            const int tap0 = (kb * 4 + fg) * TPC;
+            uint4 b = uint4{0u, 0u, 0u, 0u};
+            if (DT == AF_F32) {
+                if (tap0 < a.kt) b = *reinterpret_cast<const uint4*>(px + tap0 * plane_b);
+            } else {
+                uint2 lo = uint2{0u, 0u}, hi = uint2{0u, 0u};
+                if (tap0 < a.kt) lo = *reinterpret_cast<const uint2*>(px + tap0 * plane_b);
+                if (tap0 + 1 < a.kt) hi = *reinterpret_cast<const uint2*>(px + (tap0 + 1) * plane_b);
+                b = uint4{lo.x, lo.y, hi.x, hi.y};
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) Mma<DT>::run(wf[kb][i], b, acc[i]);
+        }
+        // BN, then the 2x2 max over positions (frow ^ 1: column partner, frow ^ 8: row partner), then ReLU
+        const bool writer = (frow & 9) == 0 && tw * 4 + (c >> 1) < a.Wo;
+        const long long opix = ((n * a.T + t) * a.Ho + ph) * a.Wo + tw * 4 + (c >> 1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f32x4 v = acc[i] * sc[i] + sf[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float x = v[e];
+                float y = __shfl_xor(x, 1); x = (y > x || y != y) ? y : x;       // NaN propagates like ATen's max_pool
+                y = __shfl_xor(x, 8); x = (y > x || y != y) ? y : x;
+                v[e] = fmaxf(x, 0.f) + (x != x ? x : 0.f);
+            }
+            if (writer) Vec4<DT>::store(a.out + (opix * 64 + i * 16 + fg * 4) * ES, v);
+        }
+    }
+}
+
+__global__ void pack_tstem_weight_kernel(const float* w, int kt, int dtype, char* out) {
+    // out[kb][tile][lane][16 B]; lane = fg*16 + frow -> channel tile*16 + frow, chunk = taps tap0.. x 4 channels
+    const int epc = dtype == AF_F32 ? 4 : 8, tpc = epc / 4, kbs = dtype == AF_F32 ? 2 : 1;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;        // (kb, tile, lane, element)
+    if (idx >= kbs * 4 * 64 * epc) return;
+    const int e = idx % epc, lane = (idx / epc) % 64, tile = (idx / epc / 64) % 4, kb = idx / epc / 64 / 4;
+    const int frow = lane & 15, fg = lane >> 4;
+    const int tap = (kb * 4 + fg) * tpc + e / 4, ch = e % 4, co = tile * 16 + frow;
+    const float v = (tap < kt && ch < 3) ? w[(co * 3 + ch) * kt + tap] : 0.f;
+    if (dtype == AF_F32) reinterpret_cast<float*>(out)[idx] = v;
+    else if (dtype == AF_BF16) reinterpret_cast<__bf16*>(out)[idx] = (__bf16)v;
+    else reinterpret_cast<_Float16*>(out)[idx] = (_Float16)v;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// transformer head (fp32)
+// tokens[b][0] = cls + pos[0];  tokens[b][1 + t] = pooled[b][t] + pos[1 + t]     (time_transformer.py:270-273)
+__global__ void tokens_assemble_kernel(const float* pooled, const float* cls, const float* pos, int n_tok, int dim,
+                                       long long total, float* out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int d = (int)(i % dim); const long long row = i / dim;
+    const int t = (int)(row % (n_tok + 1)); const long long b = row / (n_tok + 1);
+    const float x = t == 0 ? cls[d] : pooled[(b * n_tok + (t - 1)) * dim + d];
+    out[i] = x + pos[(long long)t * dim + d];
+}
+
+// nn.LayerNorm(dim, eps 1e-5): one wave per row; two-pass mean / variance in fp32 like ATen
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* x, long long x_stride, const float* gamma,
+                                                        const float* beta, int rows, int dim, float eps, float* y,
+                                                        long long y_stride) {
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* xr = x + row * x_stride;
+    float s = 0.f;
+    for (int i = lane; i < dim; i += 64) s += xr[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / dim;
+    float v = 0.f;
+    for (int i = lane; i < dim; i += 64) { const float d = xr[i] - mean; v += d * d; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    const float rstd = rsqrtf(v / dim + eps);
+    float* yr = y + row * y_stride;
+    for (int i = lane; i < dim; i += 64) yr[i] = (xr[i] - mean) * rstd * gamma[i] + beta[i];
+}
+
+// softmax(q k^T * scale) v for a handful of tokens: one workgroup per (clip, head); qkv rows are [q | k | v], each
+// heads * dim_head wide (Attention.forward, time_transformer.py:52-71: 'b n (h d) -> b h n d')
+constexpr int ATT_MAX_TOK = 64, ATT_MAX_DH = 128;
+__global__ __launch_bounds__(128) void attention_kernel(const float* qkv, int n_tok, int heads, int dh, float scale,
+                                                        float* out) {
+    extern __shared__ float sm[];                      // q,k,v [n_tok][dh] each, then scores [n_tok][n_tok]
+    const int b = blockIdx.x / heads, h = blockIdx.x % heads, tid = threadIdx.x;
+    const int inner = heads * dh;
+    float* q = sm; float* k = q + n_tok * dh; float* v = k + n_tok * dh; float* p = v + n_tok * dh;
+    for (int i = tid; i < n_tok * dh; i += blockDim.x) {
+        const int t = i / dh, d = i % dh;
+        const float* row = qkv + ((long long)b * n_tok + t) * 3 * inner + h * dh + d;
+        q[i] = row[0]; k[i] = row[inner]; v[i] = row[2 * inner];
+    }
+    __syncthreads();
+    for (int i = tid; i < n_tok * n_tok; i += blockDim.x) {
+        const int r = i / n_tok, c = i % n_tok;
+        float s = 0.f;
+        for (int d = 0; d < dh; ++d) s += q[r * dh + d] * k[c * dh + d];
+        p[i] = s * scale;
+    }
+    __syncthreads();
+    for (int r = tid; r < n_tok; r += blockDim.x) {
+        float m = -INFINITY;
+        for (int c = 0; c < n_tok; ++c) m = fmaxf(m, p[r * n_tok + c]);
+        float z = 0.f;
+        for (int c = 0; c < n_tok; ++c) { const float e = expf(p[r * n_tok + c] - m); p[r * n_tok + c] = e; z += e; }
+        const float inv = 1.f / z;
+        for (int c = 0; c < n_tok; ++c) p[r * n_tok + c] *= inv;
+    }
+    __syncthreads();
+    for (int i = tid; i < n_tok * dh; i += blockDim.x) {
+        const int r = i / dh, d = i % dh;
+        float s = 0.f;
+        for (int c = 0; c < n_tok; ++c) s += p[r * n_tok + c] * v[c * dh + d];
+        out[((long long)b * n_tok + r) * inner + h * dh + d] = s;        // 'b h n d -> b n (h d)'
+    }
+}
+
+// nn.GELU() (exact, erf form), in place
+__global__ void gelu_kernel(float* x, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const float v = x[i]; x[i] = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f)); }
+}
+
+}  // namespace af
+
+extern "C" int af_pack_tstem_weight(const float* w_oidhw, int cout, int kt, int dtype, void* out, void* stream) {
+    using namespace af;
+    AF_REQUIRE(w_oidhw && out && dtype_ok(dtype), "pack_tstem_weight: bad argument");
+    AF_REQUIRE(cout == 64 && kt >= 1 && kt <= 2 * AF_STEM_PAD_T + 1 && (kt & 1), "pack_tstem_weight: expects 64 x 3 x kt x 1 x 1, kt odd <= %d", 2 * AF_STEM_PAD_T + 1);
+    const int total = (dtype == AF_F32 ? 2 : 1) * 4 * 64 * (dtype == AF_F32 ? 4 : 8);
+    hipLaunchKernelGGL(pack_tstem_weight_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_oidhw, kt, dtype, (char*)out);
+    AF_CHECK_LAUNCH("pack_tstem_weight_kernel");
+    return AF_OK;
+}
+
+extern "C" long long af_packed_tstem_weight_bytes(int dtype) { return (dtype == AF_F32 ? 2 : 1) * 4 * 64 * 16; }
+
+extern "C" int af_tstem_conv_bn_pool_relu(const af_conv_desc* d, const void* stem_in, const void* w_packed,
+                                          const float* scale, const float* shift, void* out, void* stream) {
+    using namespace af;
+    AF_REQUIRE(d && stem_in && w_packed && scale && shift && out, "tstem: null argument");
+    AF_REQUIRE(dtype_ok(d->dtype), "tstem: bad dtype %d", d->dtype);
+    AF_REQUIRE(d->cin == 3 && d->cout == 64 && d->kh == 1 && d->kw == 1 && d->st == 1 && d->sh == 1 && d->sw == 1 &&
+                   d->ph == 0 && d->pw == 0, "tstem: expects Conv3d(3->64, [kt,1,1], stride 1)");
+    AF_REQUIRE(d->kt >= 1 && d->kt <= 2 * AF_STEM_PAD_T + 1 && (d->kt & 1) && d->pt == d->kt / 2, "tstem: bad kt/pt");
+    AF_REQUIRE(d->n > 0 && d->t > 0 && d->h >= 2 && d->w >= 2, "tstem: bad dims");
+    AF_REQUIRE(d->to == d->t && d->ho == d->h / 2 && d->wo == d->w / 2, "tstem: output dims are (t, h/2, w/2): the 2x2 pool is fused");
+    AF_REQUIRE(aligned16(stem_in) && aligned16(w_packed) && aligned16(scale) && aligned16(shift) && aligned16(out),
+               "tstem: buffers must be 16-byte aligned");
+    TStemArgs a;
+    a.in = (const char*)stem_in; a.w = (const char*)w_packed; a.scale = scale; a.shift = shift; a.out = (char*)out;
+    a.T = d->t; a.Tp = d->t + 2 * AF_STEM_PAD_T; a.Hp = d->h + 2 * AF_STEM_PAD_H; a.Wp = d->w + AF_STEM_PAD_W_TOTAL;
+    a.H = d->h; a.W = d->w; a.Ho = d->ho; a.Wo = d->wo; a.tiles_w = (d->wo + 3) / 4;
+    a.tiles = (long long)d->n * d->t * d->ho * a.tiles_w;
+    a.t_off = AF_STEM_PAD_T - d->pt; a.kt = d->kt;
+    long long blocks = (a.tiles + 4 * 8 - 1) / (4 * 8);                   // ~8 tiles per wave
+    if (blocks > 256 * 64) blocks = 256 * 64;
+    if (blocks < 1) blocks = 1;
+    hipStream_t s = (hipStream_t)stream;
+    switch (d->dtype) {
+        case AF_F32: hipLaunchKernelGGL((tstem_kernel<AF_F32>), dim3((unsigned)blocks), dim3(256), 0, s, a); break;
+        case AF_BF16: hipLaunchKernelGGL((tstem_kernel<AF_BF16>), dim3((unsigned)blocks), dim3(256), 0, s, a); break;
+        default: hipLaunchKernelGGL((tstem_kernel<AF_F16>), dim3((unsigned)blocks), dim3(256), 0, s, a); break;
+    }
+    AF_CHECK_LAUNCH("tstem_kernel");
+    return AF_OK;
+}
+
+extern "C" int af_tokens_assemble(const float* pooled, const float* cls_token, const float* pos_embedding, int clips,
+                                  int n_tok, int dim, float* out, void* stream) {
+    using namespace af;
+    AF_REQUIRE(pooled && cls_token && pos_embedding && out && clips >= 0 && n_tok > 0 && dim > 0, "tokens_assemble: bad argument");
+    const long long total = (long long)clips * (n_tok + 1) * dim;
+    if (total == 0) return AF_OK;
+    hipLaunchKernelGGL(tokens_assemble_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       pooled, cls_token, pos_embedding, n_tok, dim, total, out);
+    AF_CHECK_LAUNCH("tokens_assemble_kernel");
+    return AF_OK;
+}
+
+extern "C" int af_layernorm(const float* x, long long x_row_stride, const float* gamma, const float* beta, int rows,
+                            int dim, float eps, float* y, long long y_row_stride, void* stream) {
+    using namespace af;
+    AF_REQUIRE(x && gamma && beta && y && rows >= 0 && dim > 0, "layernorm: bad argument");
+    if (rows == 0) return AF_OK;
+    hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, x_row_stride, gamma,
+                       beta, rows, dim, eps, y, y_row_stride);
+    AF_CHECK_LAUNCH("layernorm_kernel");
+    return AF_OK;
+}
+
+extern "C" int af_attention(const float* qkv, int clips, int n_tok, int heads, int dim_head, float* out, void* stream) {
+    using namespace af;
+    AF_REQUIRE(qkv && out && clips >= 0 && heads > 0, "attention: bad argument");
+    AF_REQUIRE(n_tok > 0 && n_tok <= ATT_MAX_TOK && dim_head > 0 && dim_head <= ATT_MAX_DH,
+               "attention: at most %d tokens x %d per head (got %d x %d)", ATT_MAX_TOK, ATT_MAX_DH, n_tok, dim_head);
+    if (clips == 0) return AF_OK;
+    const int lds = (3 * n_tok * dim_head + n_tok * n_tok) * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (3 * ATT_MAX_TOK * ATT_MAX_DH + ATT_MAX_TOK * ATT_MAX_TOK) * 4);
+        if (e != hipSuccess) return set_error(AF_ERR_LAUNCH, "attention: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(attention_kernel, dim3(clips * heads), dim3(128), lds, (hipStream_t)stream, qkv, n_tok, heads, dim_head,
+                       1.0f / sqrtf((float)dim_head), out);
+    AF_CHECK_LAUNCH("attention_kernel");
+    return AF_OK;
+}
+
+extern "C" int af_gelu(float* x, long long n, void* stream) {
+    using namespace af;
+    AF_REQUIRE(x && n >= 0, "gelu: bad argument");
+    if (n == 0) return AF_OK;
+    hipLaunchKernelGGL(gelu_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, n);
+    AF_CHECK_LAUNCH("gelu_kernel");
+    return AF_OK;
+}

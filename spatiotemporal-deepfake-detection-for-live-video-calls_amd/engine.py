@@ -13,7 +13,7 @@ import torch
 
 from . import _lib
 from ._lib import Op, check, lib
-from .arch import BN_EPS, ConvSpec, NetSpec, PoolSpec, SlowFastSpec
+from .arch import BN_EPS, ConvSpec, FtcnTTSpec, NetSpec, PoolSpec, SlowFastSpec
 
 _TORCH_DTYPE = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}
 
@@ -23,6 +23,7 @@ TAG_CONV_1x1x1, TAG_CONV_Tx1x1, TAG_CONV_1x3x3, TAG_CONV_OTHER = 10, 11, 12, 13
 TAG_NAMES = {TAG_PACK: "input_pack", TAG_STEM: "stem_5x7x7", TAG_POOL: "maxpool", TAG_HEAD: "head",
              TAG_CONV_1x1x1: "conv_1x1x1", TAG_CONV_Tx1x1: "conv_3x1x1", TAG_CONV_1x3x3: "conv_1x3x3",
              TAG_CONV_OTHER: "conv_other"}
+TAG_NAMES[TAG_STEM] = "stem"
 
 
 def _conv_tag(cv: ConvSpec) -> int:
@@ -71,7 +72,7 @@ class PackedWeights:
         for cv in spec.convs():
             w = state[cv.conv + ".weight"].detach().to(device=device, dtype=torch.float32).contiguous()
             assert tuple(w.shape) == cv.weight_shape, (cv.conv, tuple(w.shape), cv.weight_shape)
-            bn = [state[cv.bn + s].detach().to(device=device, dtype=torch.float32).contiguous()
+            bn = [state[cv.bn_key + s].detach().to(device=device, dtype=torch.float32).contiguous()
                   for s in (".weight", ".bias", ".running_mean", ".running_var")]
             cpad = lib.af_padded_channels(cv.cout)           # kernels read scale/shift over the padded channel tile
             scale = torch.zeros(cpad, dtype=torch.float32, device=device)
@@ -79,7 +80,11 @@ class PackedWeights:
             check(lib.af_fold_bn(_ptr(bn[0]), _ptr(bn[1]), _ptr(bn[2]), _ptr(bn[3]), BN_EPS, cv.cout,
                                  _ptr(scale), _ptr(shift), st), "af_fold_bn")
             kt, kh, kw = cv.kernel
-            if cv.conv in stems:
+            if cv.conv in stems and isinstance(spec, FtcnTTSpec):        # temporal stem: MFMA A-fragment image
+                nbytes = lib.af_packed_tstem_weight_bytes(code)
+                packed = torch.empty(nbytes // es, dtype=_TORCH_DTYPE[dtype], device=device)
+                check(lib.af_pack_tstem_weight(_ptr(w), cv.cout, kt, code, _ptr(packed), st), "af_pack_tstem_weight")
+            elif cv.conv in stems:
                 nbytes = lib.af_packed_stem_weight_bytes(cv.cout, kt, kh, code)
                 packed = torch.empty(nbytes // es, dtype=_TORCH_DTYPE[dtype], device=device)
                 check(lib.af_pack_stem_weight(_ptr(w), cv.cout, kt, kh, kw, code, _ptr(packed), st),
@@ -95,8 +100,8 @@ class PackedWeights:
         self.w_folded, self.shift_sum, self.ones = {}, {}, {}
         for stage in _stages_of(spec):
             for blk in stage.blocks:
-                if blk.branch1 is None:
-                    continue
+                if blk.branch1 is None or blk.branch1.pool_after_bn is not None:
+                    continue                 # (FTCN: a pooled shortcut cannot share the c conv's accumulator)
                 for cv in (blk.c, blk.branch1):
                     w = state[cv.conv + ".weight"].detach().to(device=device, dtype=torch.float32).contiguous()
                     kt, kh, kw = cv.kernel
@@ -107,8 +112,36 @@ class PackedWeights:
                     self.w_folded[cv.conv] = packed
                 self.shift_sum[blk.c.conv] = (self.shift[blk.c.conv] + self.shift[blk.branch1.conv]).contiguous()
                 self.ones[blk.c.conv] = torch.ones(lib.af_padded_channels(blk.c.cout), dtype=torch.float32, device=device)
-        self.fc_w = state[spec.head + ".weight"].detach().to(device=device, dtype=torch.float32).contiguous()
-        self.fc_b = state[spec.head + ".bias"].detach().to(device=device, dtype=torch.float32).contiguous()
+        f32 = lambda k: state[k].detach().to(device=device, dtype=torch.float32).contiguous()
+        if isinstance(spec, FtcnTTSpec):
+            # transformer head, fp32 whatever the trunk's dtype: Linear weights packed for the fp32 conv kernel,
+            # bias as its `shift` (scale = ones), LayerNorm / token parameters as they are
+            h = spec.head
+            l0, l1 = h + ".transformer.layers.0.0.fn", h + ".transformer.layers.0.1.fn"
+            f32code = _lib.DTYPE_CODES["f32"]
+            self.lin = {}
+            for name, wkey, bkey in (("qkv", l0 + ".fn.to_qkv.weight", None),
+                                     ("out", l0 + ".fn.to_out.0.weight", l0 + ".fn.to_out.0.bias"),
+                                     ("ff1", l1 + ".fn.net.0.weight", l1 + ".fn.net.0.bias"),
+                                     ("ff2", l1 + ".fn.net.3.weight", l1 + ".fn.net.3.bias")):
+                w = f32(wkey)
+                cout, cin = w.shape
+                nbytes = lib.af_packed_conv_weight_bytes(cout, cin, 1, 1, 1, f32code)
+                packed = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
+                check(lib.af_pack_conv_weight(_ptr(w), cout, cin, 1, 1, 1, f32code, _ptr(packed), st), "af_pack_conv_weight")
+                cpad = lib.af_padded_channels(cout)
+                bias = torch.zeros(cpad, dtype=torch.float32, device=device)
+                if bkey is not None:
+                    bias[:cout] = f32(bkey)
+                self.lin[name] = (packed, torch.ones(cpad, dtype=torch.float32, device=device), bias, cin, cout)
+            self.ln = {"attn": (f32(l0 + ".norm.weight"), f32(l0 + ".norm.bias")),
+                       "ff": (f32(l1 + ".norm.weight"), f32(l1 + ".norm.bias")),
+                       "head": (f32(h + ".mlp_head.0.weight"), f32(h + ".mlp_head.0.bias"))}
+            self.cls_token = f32(h + ".cls_token").reshape(-1)
+            self.pos_embedding = f32(h + ".pos_embedding").reshape(spec.tokens + 1, spec.dim)
+            self.fc_w, self.fc_b = f32(h + ".mlp_head.1.weight"), f32(h + ".mlp_head.1.bias")
+        else:
+            self.fc_w, self.fc_b = f32(spec.head + ".weight"), f32(spec.head + ".bias")
         torch.cuda.current_stream(device).synchronize()      # sources may be freed by the caller
 
 
@@ -135,16 +168,35 @@ class _Plan:
             self.add(kind="conv", cv=blk.a, din=d, dout=da, src=cur, dst=a_buf); self.need(a_buf, da, blk.a.cout)
             db = blk.b.out_dims(*da)
             self.add(kind="conv", cv=blk.b, din=da, dout=db, src=a_buf, dst=b_buf); self.need(b_buf, db, blk.b.cout)
+            c_src, res_src = b_buf, cur
+            if blk.b.pool_after_bn is not None:
+                # FTCN: conv -> BN -> MaxPool3d((1,2,2)) -> ReLU; the conv launch applies BN + ReLU (max and ReLU
+                # commute), the pool is its own launch into the (now free) a buffer
+                pb = blk.b.pool_after_bn
+                dbp = _pool_out(db, pb)
+                self.add(kind="pool", pool=pb, ch=blk.b.cout, din=db, dout=dbp, src=b_buf, dst=a_buf)
+                self.need(a_buf, dbp, blk.b.cout)
+                db, c_src = dbp, a_buf
+            if blk.branch1 is not None and blk.branch1.pool_after_bn is not None:
+                # pooled projection shortcut: conv + BN, pool, then it is the residual of the c conv
+                p1 = blk.branch1.pool_after_bn
+                d1 = blk.branch1.out_dims(*d)
+                d1p = _pool_out(d1, p1)
+                self.add(kind="conv", cv=blk.branch1, din=d, dout=d1, src=cur, dst="R0"); self.need("R0", d1, blk.branch1.cout)
+                self.add(kind="pool", pool=p1, ch=blk.branch1.cout, din=d1, dout=d1p, src="R0", dst="R1")
+                self.need("R1", d1p, blk.branch1.cout)
+                res_src = "R1"
             dc = blk.c.out_dims(*db)
             ld = last_ld if (last and last_ld) else blk.c.cout
             # the temporal max-pool after s2 rides in the epilogue of s2's last conv when it can
             tp = tpool_last and last and blk.branch1 is None and dc[0] % 2 == 0
             dstore = (dc[0] // 2,) + tuple(dc[1:]) if tp else dc
-            if blk.branch1 is not None:      # c conv + projection shortcut in one launch; no shortcut tensor
+            if blk.branch1 is not None and blk.branch1.pool_after_bn is None:
+                # c conv + projection shortcut in one launch; no shortcut tensor
                 assert blk.branch1.out_dims(*d) == dc
-                self.add(kind="dual", cv=blk.c, cv2=blk.branch1, din=db, din2=d, dout=dc, src=b_buf, src2=cur, dst=nxt, ld=ld)
+                self.add(kind="dual", cv=blk.c, cv2=blk.branch1, din=db, din2=d, dout=dc, src=c_src, src2=cur, dst=nxt, ld=ld)
             else:
-                self.add(kind="conv", cv=blk.c, din=db, dout=dc, src=b_buf, dst=nxt, res=cur, ld=ld, tpool=tp)
+                self.add(kind="conv", cv=blk.c, din=db, dout=dc, src=c_src, dst=nxt, res=res_src, ld=ld, tpool=tp)
             self.need(nxt, dstore, ld)
             cur, nxt = nxt, cur
             d, c = dstore, blk.c.cout
@@ -164,6 +216,8 @@ class Engine:
         plan = _Plan(batch)
         if isinstance(spec, SlowFastSpec):
             self._plan_slowfast(plan, spec, T, H, W)
+        elif isinstance(spec, FtcnTTSpec):
+            self._plan_ftcn(plan, spec, T, H, W)
         else:
             self._plan_i3d(plan, spec, T, H, W)
         self._materialise(plan)
@@ -200,6 +254,32 @@ class Engine:
             raise ValueError("input %s too small for the head pool %s" % ((T, H, W), hp))
         self.head_dims, self.head_width = dh, c
         plan.add(kind="head", pool=hp, ch=c, din=d, dout=dh, src=cur)
+
+    def _plan_ftcn(self, plan: _Plan, spec: FtcnTTSpec, T, H, W):
+        """FTCN-TT (reference i3d_temporal_var_fix_dropout_tt_cfg.py:290-359): temporal stem, s2..s4 with every spatial
+        kernel 1x1, per-frame average-pooled tokens, one pre-norm transformer layer, LayerNorm + Linear on the class
+        token (time_transformer.py:268-281)."""
+        self.inputs = [("IN", (T, H, W), 1)]
+        cur, nxt = "P0", "P1"
+        d = _pool_out(spec.stem.out_dims(T, H, W), spec.stem.pool_after_bn)
+        plan.add(kind="tstem", cv=spec.stem, din=(T, H, W), dout=d, src="IN", dst=cur); plan.need(cur, d, spec.stem.cout)
+        d2 = _pool_out(d, spec.stem_pool)
+        plan.add(kind="pool", pool=spec.stem_pool, ch=spec.stem.cout, din=d, dout=d2, src=cur, dst=nxt); plan.need(nxt, d2, spec.stem.cout)
+        cur, nxt, d = nxt, cur, d2
+        fuse_tpool = _is_pool(spec.pool_after_s2, (2, 1, 1), (2, 1, 1), (0, 0, 0))
+        c = spec.stem.cout
+        for si, stage in enumerate(spec.stages):
+            d, c, cur, nxt = plan.stage(stage, d, cur, nxt, "A", "B", tpool_last=(fuse_tpool and si == 0))
+            if si == 0 and not plan.entries[-1].get("tpool"):
+                dp = _pool_out(d, spec.pool_after_s2)
+                plan.add(kind="pool", pool=spec.pool_after_s2, ch=c, din=d, dout=dp, src=cur, dst=nxt); plan.need(nxt, dp, c)
+                cur, nxt, d = nxt, cur, dp
+        # TransformerHead 'time' patches (:133-135): AvgPool3d((1, S, S)) sized from the crop, one token per frame
+        if tuple(d[1:]) != tuple(spec.token_pool[1:]) or d[0] != spec.tokens or c != spec.dim:
+            raise ValueError("FTCN-TT head expects a (%d,%d,%d)x%d feature map, got %s x %d"
+                             % (spec.tokens, spec.token_pool[1], spec.token_pool[2], spec.dim, d, c))
+        self.head_dims, self.head_width = (1, 1, 1), spec.dim
+        plan.add(kind="tt_head", ch=c, din=d, src=cur)
 
     def _plan_slowfast(self, plan: _Plan, spec: SlowFastSpec, T, H, W):
         if T % spec.alpha:
@@ -259,7 +339,7 @@ class Engine:
         self.logits = torch.empty((batch, self.head_positions * spec.num_classes), dtype=torch.float32, device=device)
 
         n_pack = len(self.inputs)
-        self.n_ops = n_pack + len(plan.entries)
+        self.n_ops = n_pack + len(plan.entries) + (self.TT_HEAD_OPS - 1 if isinstance(spec, FtcnTTSpec) else 0)
         self.ops = (Op * self.n_ops)()
         self.op_names: List[str] = []
         self.op_macs: List[int] = []
@@ -295,9 +375,13 @@ class Engine:
                 op.in_ = self.buf[e["src"]].data_ptr()
             if "dst" in e:
                 op.out = self.buf[e["dst"]].data_ptr() + e.get("ch_off", 0) * es
-            if kind in ("stem", "stem_pool", "conv"):
+            if kind == "tt_head":
+                self._materialise_tt_head(n_pack + k, e)
+                continue
+            if kind in ("stem", "stem_pool", "conv", "tstem"):
                 cv: ConvSpec = e["cv"]
-                op.kind = {"stem": _lib.AF_OP_STEM, "stem_pool": _lib.AF_OP_STEM_POOL}.get(kind, _lib.AF_OP_CONV)
+                op.kind = {"stem": _lib.AF_OP_STEM, "stem_pool": _lib.AF_OP_STEM_POOL,
+                           "tstem": _lib.AF_OP_TSTEM}.get(kind, _lib.AF_OP_CONV)
                 op.tag = TAG_STEM if kind != "conv" else _conv_tag(cv)
                 # a, b, stems and laterals carry their own ReLU; c (final_bn) takes the block's add + ReLU; the
                 # projection shortcut has neither (resnet_helper.py:311-326, 438-444; video_model_builder.py:136-143)
@@ -360,6 +444,91 @@ class Engine:
                 self.op_macs.append(0)
             else:
                 raise KeyError(kind)
+
+    TT_HEAD_OPS = 12
+
+    def _materialise_tt_head(self, first: int, e):
+        """The FTCN-TT head as TT_HEAD_OPS ops starting at ops[first] (fp32 buffers of its own)."""
+        spec, w, batch, dev = self.spec, self.weights, self.batch, self.device
+        n1, dim, inner = spec.tokens + 1, spec.dim, spec.heads * spec.dim_head
+        rows = batch * n1
+        fb = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        self.tokens_pooled = fb(batch, spec.tokens, dim)
+        self.fbuf = {"x": fb(rows, dim), "h": fb(rows, dim), "qkv": fb(rows, 3 * inner), "att": fb(rows, inner),
+                     "x2": fb(rows, dim), "ff": fb(rows, spec.mlp_dim), "x3": fb(rows, dim)}
+        f32code = _lib.DTYPE_CODES["f32"]
+        i = [first]
+
+        def nxt(name, tag=TAG_HEAD, macs=0):
+            op = self.ops[i[0]]
+            i[0] += 1
+            op.tag = tag
+            self.op_names.append("tt_head." + name)
+            self.op_macs.append(macs)
+            if len(self.op_dst) < len(self.op_names):
+                self.op_dst.append(None)
+            return op
+
+        def linear(name, key, src, dst, res=None):
+            packed, ones, bias, cin, cout = w.lin[key]
+            op = nxt(name, TAG_CONV_1x1x1, rows * cin * cout)
+            op.kind = _lib.AF_OP_CONV
+            cd = op.conv
+            cd.n, cd.t, cd.h, cd.w, cd.cin, cd.cout = 1, 1, 1, rows, cin, cout
+            cd.kt = cd.kh = cd.kw = cd.st = cd.sh = cd.sw = 1
+            cd.pt = cd.ph = cd.pw = 0
+            cd.to, cd.ho, cd.wo = 1, 1, rows
+            cd.relu, cd.dtype, cd.tpool = 0, f32code, 0
+            op.in_, op.out = self.fbuf[src].data_ptr(), self.fbuf[dst].data_ptr()
+            op.weight, op.scale, op.shift = packed.data_ptr(), ones.data_ptr(), bias.data_ptr()
+            op.residual = self.fbuf[res].data_ptr() if res else None
+            op.out_ld = cout
+
+        def layernorm(name, key, src, dst, n_rows, x_stride, y_stride):
+            op = nxt(name)
+            op.kind = _lib.AF_OP_LAYERNORM
+            op.in_, op.out = src.data_ptr(), dst.data_ptr()
+            op.scale, op.shift = w.ln[key][0].data_ptr(), w.ln[key][1].data_ptr()
+            op.pool.n, op.pool.c, op.pool.h, op.pool.w = n_rows, dim, x_stride, y_stride
+
+        op = nxt("avgpool_tokens")                                         # (B, T/2, dim) per-frame tokens
+        op.kind = _lib.AF_OP_AVGPOOL
+        pd = op.pool
+        pd.n, (pd.t, pd.h, pd.w), pd.c = batch, e["din"], e["ch"]
+        pd.kt, pd.kh, pd.kw = spec.token_pool
+        pd.st = pd.sh = pd.sw = 1
+        pd.pt = pd.ph = pd.pw = 0
+        pd.to, pd.ho, pd.wo = e["din"][0], 1, 1
+        pd.dtype = self.code
+        op.in_, op.out, op.out_ld = self.buf[e["src"]].data_ptr(), self.tokens_pooled.data_ptr(), dim
+        op = nxt("tokens")                                                 # class token + position embedding
+        op.kind = _lib.AF_OP_TOKENS
+        op.in_, op.weight, op.scale = self.tokens_pooled.data_ptr(), w.cls_token.data_ptr(), w.pos_embedding.data_ptr()
+        op.pool.n, op.pool.t, op.pool.c = batch, spec.tokens, dim
+        op.out = self.fbuf["x"].data_ptr()
+        layernorm("attn_norm", "attn", self.fbuf["x"], self.fbuf["h"], rows, dim, dim)
+        linear("to_qkv", "qkv", "h", "qkv")
+        op = nxt("attention")
+        op.kind = _lib.AF_OP_ATTENTION
+        op.in_, op.out = self.fbuf["qkv"].data_ptr(), self.fbuf["att"].data_ptr()
+        op.pool.n, op.pool.t, op.pool.h, op.pool.w = batch, n1, spec.heads, spec.dim_head
+        linear("to_out", "out", "att", "x2", res="x")                      # Residual(PreNorm(Attention))
+        layernorm("ff_norm", "ff", self.fbuf["x2"], self.fbuf["h"], rows, dim, dim)
+        linear("ff1", "ff1", "h", "ff")
+        op = nxt("gelu")
+        op.kind = _lib.AF_OP_GELU
+        op.out = self.fbuf["ff"].data_ptr()
+        op.pool.n, op.pool.c = rows, spec.mlp_dim
+        linear("ff2", "ff2", "ff", "x3", res="x2")                         # Residual(PreNorm(FeedForward))
+        # mlp_head on the class token (row 0 of every clip): LayerNorm -> Linear; `pooled` = the Linear's input
+        layernorm("head_norm", "head", self.fbuf["x3"], self.pooled, batch, n1 * dim, dim)
+        op = nxt("head_linear")
+        op.kind = _lib.AF_OP_LINEAR
+        op.in_, op.weight, op.scale = self.pooled.data_ptr(), w.fc_w.data_ptr(), w.fc_b.data_ptr()
+        op.pool.n, op.pool.c = batch, dim
+        op.num_classes = spec.num_classes
+        op.out = self.logits.data_ptr()
+        assert i[0] - first == self.TT_HEAD_OPS
 
     # -- input binding -------------------------------------------------------------------------------------
     def _bind_f32(self, i: int, x: torch.Tensor, tstride: int = 1):
@@ -429,7 +598,7 @@ class Engine:
         op = self.ops[op_index]
         if op.kind == _lib.AF_OP_STEM_POOL:
             shape = (op.conv.n, op.conv.to, (op.conv.ho - 1) // 2 + 1, (op.conv.wo - 1) // 2 + 1, op.conv.cout)
-        elif op.kind in (_lib.AF_OP_STEM, _lib.AF_OP_CONV, _lib.AF_OP_CONV_DUAL):
+        elif op.kind in (_lib.AF_OP_STEM, _lib.AF_OP_CONV, _lib.AF_OP_CONV_DUAL, _lib.AF_OP_TSTEM):
             ld = op.out_ld or op.conv.cout
             shape = (op.conv.n, op.conv.to // 2 if op.conv.tpool else op.conv.to, op.conv.ho, op.conv.wo, ld)
         elif op.kind == _lib.AF_OP_MAXPOOL:
