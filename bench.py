@@ -32,7 +32,8 @@ def cpu_baseline(sd, u8, threads_all, model="i3d"):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import i3d_oracle as oracle
     x = oracle.normalize(u8)
-    fwd = oracle.forward if model == "i3d" else (lambda s_, x_: oracle.slowfast_forward(s_, x_[:, :, ::8], x_))
+    fwd = {"i3d": oracle.forward, "ftcn_tt": oracle.ftcn_forward,
+           "slowfast": (lambda s_, x_: oracle.slowfast_forward(s_, x_[:, :, ::8], x_))}[model]
     torch.set_num_threads(threads_all)
     with torch.no_grad():
         fwd(sd, x[:1])                                              # warm-up (first call pages oneDNN in)
@@ -75,8 +76,9 @@ def main():
     ap.add_argument("--batch", type=int, default=16, help="clips per GPU")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--cpu-clips", type=int, default=4, help="clips in the CPU baseline sample (0 = skip)")
-    ap.add_argument("--model", default="i3d", choices=["i3d", "slowfast"],
-                    help="i3d = the i3d_ori plugin (BASELINE metric); slowfast = the two-pathway SlowFast-R50 (next row)")
+    ap.add_argument("--model", default="i3d", choices=["i3d", "slowfast", "ftcn_tt"],
+                    help="i3d = the i3d_ori plugin (BASELINE metric); slowfast = the two-pathway SlowFast-R50, ftcn_tt = the "
+                         "reference's second plugin (next rows of SURVEY 8f)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--layers-json", default=None, help="write per-layer device times / rates to this file")
     args = ap.parse_args()
@@ -104,6 +106,14 @@ def main():
         clf.load_state_dict(sd)
         clf = clf.to(dev).eval()
         net = clf
+    elif args.model == "ftcn_tt":
+        from af_mi355x.arch import ftcn_tt_spec
+        from af_mi355x.classifier import FtcnTTClassifier
+        sd = synth.synthetic_state_dict(ftcn_tt_spec(), seed=0)
+        clf = FtcnTTClassifier(precision=args.dtype)
+        clf.network.load_state_dict(sd)
+        clf = clf.to(dev).eval()
+        net = clf.network
     else:
         sd = synth.synthetic_state_dict(seed=0)
         clf = Classifier(precision=args.dtype)
@@ -146,7 +156,8 @@ def main():
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "%s forward, batch=%d clips/GPU of 32x3x224x224, synthetic checkpoint W(0), "
                                "model.forward(clip) on HBM-resident fp32 input"
-                               % ("AltFreezing i3d_ori (I3D-R50)" if args.model == "i3d" else "SlowFast-R50 (alpha 8)", B),
+                               % ({"i3d": "AltFreezing i3d_ori (I3D-R50)", "slowfast": "SlowFast-R50 (alpha 8)",
+                                   "ftcn_tt": "FTCN-TT plugin (i3d_temporal_var_fix_dropout_tt_cfg, ftcn_tt.yaml)"}[args.model], B),
                    "global_batch": world * B, "parallelism": "dp%d + all-gather of logits" % world},
     }
 

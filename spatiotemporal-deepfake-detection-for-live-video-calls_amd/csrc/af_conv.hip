@@ -512,6 +512,9 @@ static int pick_variant(int cout, int cin, int taps, int dtype, long long M, int
         const long long big = (M + 511) / 512, v0 = (M + 255) / 256;
         if (big >= 128 && (double)((big + 255) / 256) < 0.615 * (double)((v0 + 255) / 256) + 0.05) return VAR_128x512;
     }
+    // a handful of rows (the FTCN-TT head: 17 tokens per clip): the smallest tile, so that at least the channel
+    // dimension spreads over the CUs
+    if ((M + 255) / 256 * (cout / (wide ? 128 : 64)) < 64) return VAR_64x128;
     if (wide && !short_k && ksteps <= 8 && cout >= 512) return VAR_128x128_R2;   // wide-output streams, 4..8 K-steps
     return wide ? (short_k ? VAR_128x128 : VAR_128x256) : (short_k ? VAR_64x128 : VAR_64x256);
 }

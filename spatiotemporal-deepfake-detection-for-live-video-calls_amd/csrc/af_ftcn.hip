@@ -22,15 +22,17 @@ struct TStemArgs {
     char* out;           // [N][T][H/2][W/2][64]
     int T, Hp, Wp, Tp;   // frames; padded input dims
     int H, W, Ho, Wo;    // conv image; pooled image
-    int tiles_w;         // ceil(Wo / 4)
+    int tiles_w;         // ceil(Wo / 16)
     long long tiles;     // N * T * Ho * tiles_w
     int t_off;           // first padded frame of tap 0 for output frame 0 (PAD_T - kt/2)
     int kt;
 };
 
-// A wave owns tiles of 2 x 8 conv positions = 1 x 4 pooled pixels; lane = (fg = k-group, frow = position: row
-// frow >> 3, column frow & 7).  16-bit: one K-block of 32 = 8 tap slots x 4 channels, lane group fg holds taps
-// 2fg, 2fg+1.  fp32: K-blocks of 16 = 4 tap slots, lane group fg holds tap 4*kb + fg.
+// A wave owns tiles of 16 consecutive pooled pixels of one row = 2 x 32 conv positions, as FOUR position tiles: tile
+// (dy, dx) holds window member (dy, dx) of each of the 16 pooled pixels, so the 2x2 max is an elementwise max of four
+// accumulators (no cross-lane traffic) and every lane stores.  Lane = (fg = k-group, frow = pooled pixel in the tile).
+// 16-bit: one K-block of 32 = 8 tap slots x 4 channels, lane group fg holds taps 2fg, 2fg+1.  fp32: K-blocks of
+// 16 = 4 tap slots, lane group fg holds tap 4*kb + fg.
 template <int DT>
 __global__ __launch_bounds__(256) void tstem_kernel(const TStemArgs a) {
     typedef Elem<DT> E;
@@ -54,49 +56,55 @@ __global__ __launch_bounds__(256) void tstem_kernel(const TStemArgs a) {
         sf[i] = *reinterpret_cast<const f32x4*>(a.shift + i * 16 + fg * 4);
     }
     const long long row_b = (long long)a.Wp * PIXB, plane_b = row_b * a.Hp;
-    const int r = frow >> 3, c = frow & 7;
 
     for (long long tile = wave0; tile < a.tiles; tile += nwaves) {
         const int tw = (int)(tile % a.tiles_w); long long q = tile / a.tiles_w;
         const int ph = (int)(q % a.Ho); q /= a.Ho;
         const int t = (int)(q % a.T); const long long n = q / a.T;
-        int w = tw * 8 + c; if (w > a.W - 1) w = a.W - 1;               // ragged last tile: clamped, never stored
-        const int h = 2 * ph + r;
-        const char* px = a.in + ((n * a.Tp + t + a.t_off) * plane_b) + (long long)(h + AF_STEM_PAD_H) * row_b +
-                         (long long)(w + AF_STEM_PAD_W_LEFT) * PIXB;
-        f32x4 acc[4];
+        int pw = tw * 16 + frow;                                        // pooled column of this lane
+        const bool live = pw < a.Wo;
+        if (!live) pw = a.Wo - 1;                                       // ragged last tile: clamped, never stored
+        const char* px = a.in + ((n * a.Tp + t + a.t_off) * plane_b) + (long long)(2 * ph + AF_STEM_PAD_H) * row_b +
+                         (long long)(2 * pw + AF_STEM_PAD_W_LEFT) * PIXB;
+        f32x4 acc[4][4];                                                // [window member][channel tile]
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[m][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) {
             // this lane's chunk: TPC consecutive taps starting at tap0; taps >= kt have zero weights and are not read
             const int tap0 = (kb * 4 + fg) * TPC;
-            uint4 b = uint4{0u, 0u, 0u, 0u};
-            if (DT == AF_F32) {
-                if (tap0 < a.kt) b = *reinterpret_cast<const uint4*>(px + tap0 * plane_b);
-            } else {
-                uint2 lo = uint2{0u, 0u}, hi = uint2{0u, 0u};
-                if (tap0 < a.kt) lo = *reinterpret_cast<const uint2*>(px + tap0 * plane_b);
-                if (tap0 + 1 < a.kt) hi = *reinterpret_cast<const uint2*>(px + (tap0 + 1) * plane_b);
-                b = uint4{lo.x, lo.y, hi.x, hi.y};
-            }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) Mma<DT>::run(wf[kb][i], b, acc[i]);
+            for (int m = 0; m < 4; ++m) {
+                const char* p = px + (m >> 1) * row_b + (m & 1) * PIXB;
+                uint4 b = uint4{0u, 0u, 0u, 0u};
+                if (DT == AF_F32) {
+                    if (tap0 < a.kt) b = *reinterpret_cast<const uint4*>(p + tap0 * plane_b);
+                } else {
+                    uint2 lo = uint2{0u, 0u}, hi = uint2{0u, 0u};
+                    if (tap0 < a.kt) lo = *reinterpret_cast<const uint2*>(p + tap0 * plane_b);
+                    if (tap0 + 1 < a.kt) hi = *reinterpret_cast<const uint2*>(p + (tap0 + 1) * plane_b);
+                    b = uint4{lo.x, lo.y, hi.x, hi.y};
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) Mma<DT>::run(wf[kb][i], b, acc[m][i]);
+            }
         }
-        // BN, then the 2x2 max over positions (frow ^ 1: column partner, frow ^ 8: row partner), then ReLU
-        const bool writer = (frow & 9) == 0 && tw * 4 + (c >> 1) < a.Wo;
-        const long long opix = ((n * a.T + t) * a.Ho + ph) * a.Wo + tw * 4 + (c >> 1);
+        // BN on each window member, 2x2 max (NaN propagates like ATen's max_pool), ReLU, store 4 channels per tile
+        const long long opix = ((n * a.T + t) * a.Ho + ph) * a.Wo + pw;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            f32x4 v = acc[i] * sc[i] + sf[i];
+            f32x4 v = acc[0][i] * sc[i] + sf[i];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float x = v[e];
-                float y = __shfl_xor(x, 1); x = (y > x || y != y) ? y : x;       // NaN propagates like ATen's max_pool
-                y = __shfl_xor(x, 8); x = (y > x || y != y) ? y : x;
-                v[e] = fmaxf(x, 0.f) + (x != x ? x : 0.f);
+            for (int m = 1; m < 4; ++m) {
+                const f32x4 y = acc[m][i] * sc[i] + sf[i];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (y[e] > v[e] || y[e] != y[e]) ? y[e] : v[e];
             }
-            if (writer) Vec4<DT>::store(a.out + (opix * 64 + i * 16 + fg * 4) * ES, v);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] != v[e] ? v[e] : fmaxf(v[e], 0.f);
+            if (live) Vec4<DT>::store(a.out + (opix * 64 + i * 16 + fg * 4) * ES, v);
         }
     }
 }
@@ -223,10 +231,10 @@ extern "C" int af_tstem_conv_bn_pool_relu(const af_conv_desc* d, const void* ste
     TStemArgs a;
     a.in = (const char*)stem_in; a.w = (const char*)w_packed; a.scale = scale; a.shift = shift; a.out = (char*)out;
     a.T = d->t; a.Tp = d->t + 2 * AF_STEM_PAD_T; a.Hp = d->h + 2 * AF_STEM_PAD_H; a.Wp = d->w + AF_STEM_PAD_W_TOTAL;
-    a.H = d->h; a.W = d->w; a.Ho = d->ho; a.Wo = d->wo; a.tiles_w = (d->wo + 3) / 4;
+    a.H = d->h; a.W = d->w; a.Ho = d->ho; a.Wo = d->wo; a.tiles_w = (d->wo + 15) / 16;
     a.tiles = (long long)d->n * d->t * d->ho * a.tiles_w;
     a.t_off = AF_STEM_PAD_T - d->pt; a.kt = d->kt;
-    long long blocks = (a.tiles + 4 * 8 - 1) / (4 * 8);                   // ~8 tiles per wave
+    long long blocks = (a.tiles + 4 * 4 - 1) / (4 * 4);                   // ~4 tiles per wave
     if (blocks > 256 * 64) blocks = 256 * 64;
     if (blocks < 1) blocks = 1;
     hipStream_t s = (hipStream_t)stream;

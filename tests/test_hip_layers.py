@@ -170,7 +170,7 @@ CONV_CASES = [
 ]
 EXPECT_VARIANT = {"tile256_1x3x3_res": 6, "tile256_ragged_m": 6, "tile512_1x3x3_res": 7, "tile512_ragged_m": 7,
                   "t311_64to64_T32": 8, "t311_256to64_T16": 8, "t311_256to64_T32_many": 8,
-                  "t311_256to128_T16": {"f32": 0, "f16": 8, "bf16": 8}}
+                  "t311_256to128_T16": {"f32": 3, "f16": 8, "bf16": 8}}
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
