@@ -60,11 +60,15 @@ def pmc_traffic(kernel_label, dtype):
         return None, None
     m = re.search(r"BN=(\d+),BM=(\d+)", kernel_label)
     data = json.load(open(files[-1]))["kernels"]
+    tot, n = 0.0, 0                      # launch-weighted over every instantiation that carries this label
     for name, v in data.items():
-        if m and re.search(r"conv_igemm_kernel<\d+, %s, %s," % (m.group(1), m.group(2)), name):
-            return v["hbm_bytes_per_launch"], os.path.relpath(files[-1], ROOT)
-        if not m and kernel_label in name:
-            return v["hbm_bytes_per_launch"], os.path.relpath(files[-1], ROOT)
+        hit = (m and re.search(r"conv_igemm_kernel<\d+, %s, %s," % (m.group(1), m.group(2)), name)) or \
+              (not m and kernel_label.split("<")[0].replace("_kernel", "").replace("_c64", "") + "_" in name)
+        if hit:
+            tot += v["hbm_bytes_per_launch"] * v["launches_profiled"]
+            n += v["launches_profiled"]
+    if n:
+        return tot / n, os.path.relpath(files[-1], ROOT)
     return None, None
 
 
@@ -179,10 +183,15 @@ def main():
             eng_bytes, kernel_ops = {}, {}
             for i in range(eng.n_ops):
                 op = eng.ops[i]
-                if op.kind in (_lib.AF_OP_CONV, _lib.AF_OP_STEM, _lib.AF_OP_CONV_DUAL):
+                if op.kind in (_lib.AF_OP_CONV, _lib.AF_OP_STEM, _lib.AF_OP_CONV_DUAL, _lib.AF_OP_STEM_POOL, _lib.AF_OP_TSTEM):
                     cd = op.conv
                     mm = cd.n * cd.to * cd.ho * cd.wo
-                    eng_bytes[i] = es * (cd.n * cd.t * cd.h * cd.w * cd.cin + mm * cd.cout * (2 if op.residual else 1)
+                    if op.kind == _lib.AF_OP_STEM_POOL:          # only the pooled tensor is written
+                        mm = cd.n * cd.to * ((cd.ho - 1) // 2 + 1) * ((cd.wo - 1) // 2 + 1)
+                    elif cd.tpool:
+                        mm //= 2
+                    eng_bytes[i] = es * (cd.n * cd.t * cd.h * cd.w * cd.cin + mm * cd.cout
+                                         + (cd.n * cd.to * cd.ho * cd.wo * cd.cout if op.residual else 0)
                                          + cd.cout * cd.cin * cd.kt * cd.kh * cd.kw)
                     if op.kind == _lib.AF_OP_CONV_DUAL:
                         c2 = op.conv2
@@ -194,8 +203,9 @@ def main():
                     import ctypes as C
                     d2 = C.byref(op.conv2) if op.kind == _lib.AF_OP_CONV_DUAL else None
                     kname = _lib.lib.af_conv_variant_name(_lib.lib.af_conv_variant(C.byref(op.conv), d2)).decode()
-                elif op.kind == _lib.AF_OP_STEM:
-                    kname = "stem_kernel"
+                elif op.kind in (_lib.AF_OP_STEM, _lib.AF_OP_STEM_POOL, _lib.AF_OP_TSTEM):
+                    kname = {_lib.AF_OP_STEM: "stem_kernel", _lib.AF_OP_STEM_POOL: "stem_pool_kernel",
+                             _lib.AF_OP_TSTEM: "tstem_kernel"}[op.kind]
                 else:
                     continue
                 k = per_kernel.setdefault(kname, {"ms": 0.0, "macs": 0, "launches": 0})
@@ -221,13 +231,23 @@ def main():
             dom = max(per_kernel, key=lambda k: per_kernel[k]["ms"])
             d = per_kernel[dom]
             dom_ops = kernel_ops[dom]
-            achieved = 2 * d["macs"] / (d["ms"] * 1e-3) / 1e12
+            # which roof bounds this kernel: its algorithmic intensity against the ridge of the machine
+            alg_bytes_total = sum(eng_bytes[i] for i in dom_ops)
+            intensity = 2 * d["macs"] / max(alg_bytes_total, 1)
+            ridge = PEAK_TFLOPS[args.dtype] * 1e12 / (HBM_PEAK_GBS * 1e9)
+            if intensity >= ridge:
+                achieved = 2 * d["macs"] / (d["ms"] * 1e-3) / 1e12
+                peak, unit, bound = PEAK_TFLOPS[args.dtype], "TFLOP/s", "mfma"
+            else:
+                achieved = alg_bytes_total / (d["ms"] * 1e-3) / 1e9
+                peak, unit, bound = HBM_PEAK_GBS, "GB/s", "hbm"
             line["roofline"] = {
-                "bound": "mfma", "kernel": dom, "launches_per_step": d["launches"],
+                "bound": bound, "kernel": dom, "launches_per_step": d["launches"],
                 "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2),
                 "algorithmic_gflop_per_launch": round(2 * d["macs"] / d["launches"] / 1e9, 3),
-                "achieved": round(achieved, 2), "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_TFLOPS[args.dtype], 4), "traffic": None,
+                "algorithmic_intensity_flop_per_byte": round(intensity, 1),
+                "achieved": round(achieved, 2), "peak": peak, "unit": unit,
+                "frac": round(achieved / peak, 4), "traffic": None,
             }
             tr, src = pmc_traffic(dom, args.dtype)
             if tr is not None:
