@@ -1,3 +1,5 @@
+// Stand-alone probe (hipcc --offload-arch=gfx950 -O2, run on the GPU box): checks what the conv kernels rely on for
+// `buffer_load_dwordx4 ... offen lds` - LDS image = M0 base + lane * 16, SGPR offset added, out-of-range lanes write zeros.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>

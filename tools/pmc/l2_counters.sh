@@ -1,3 +1,5 @@
+# Run ON THE GPU BOX (through gpurun) from the repo root:  bash tools/pmc/l2_counters.sh
+# L2 hit / miss / request counters per kernel (two separate --pmc passes); results under gpurun_out/l2/.
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out/l2
 mkdir -p $OUT
