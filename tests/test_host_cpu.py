@@ -38,6 +38,33 @@ def test_slowfast_state_dict_layout():
     assert m.resnet.head.projection.in_features == 2304
 
 
+def test_ftcn_tt_plugin_layout_and_load(tmp_path):
+    """FTCN-TT drop-in: the module tree reproduces the reference plugin's 275-key state_dict (BNs followed by a pool
+    under `<bn>.0`, `resnet.head.time_T.*`; asserted key-by-key against the reference in oracle/gen_golden.py --ftcn
+    and pinned here through the fixture's key / parameter counts), its last nn.Linear is mlp_head.1, and load() has the
+    ModelBase semantics (wrapper key + one prefix stripped)."""
+    from af_mi355x.classifier import FtcnTTClassifier
+    g = load_json("f6_ftcn.json")
+    c = FtcnTTClassifier().eval()
+    sd = c.network.state_dict()
+    lay = arch.state_dict_layout(arch.ftcn_tt_spec())
+    assert [k for k, _, _ in lay] == list(sd.keys()) and len(sd) == g["num_keys"] == 275
+    assert all(tuple(sd[k].shape) == tuple(sh) for k, sh, _ in lay)
+    assert sum(p.numel() for p in c.parameters()) == g["num_params"]
+    assert "resnet.s1.pathway0_stem.bn.0.weight" in sd and "resnet.s3.pathway0_res0.branch1_bn.0.running_var" in sd
+    last = [m for m in c.network.modules() if isinstance(m, torch.nn.Linear)][-1]
+    assert last is getattr(c.network.resnet.head.time_T.mlp_head, "1") and last.in_features == 1024
+    w = synth.synthetic_state_dict(arch.ftcn_tt_spec(), seed=g["weights_seed"])
+    assert synth.state_dict_sha256(w) == g["weights_sha256"]
+    path = os.path.join(tmp_path, "ftcn.pth")
+    torch.save({"model_state_dict": {"network." + k: v for k, v in w.items()}}, path)
+    assert c.load(path) == (True, -1)
+    assert torch.equal(c.network.state_dict()["resnet.head.time_T.pos_embedding"], w["resnet.head.time_T.pos_embedding"])
+    assert c.load(os.path.join(tmp_path, "missing.pth")) == (False, -1)
+    with pytest.raises(RuntimeError):
+        c(torch.zeros(1, 3, 32, 224, 224))               # CPU tensor: no fallback
+
+
 def test_last_linear_is_head_projection(clf):
     lin = [m for m in clf.modules() if isinstance(m, torch.nn.Linear)][-1]
     assert lin is clf.network.resnet.head.projection and lin.in_features == 2048 and lin.out_features == 1
