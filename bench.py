@@ -189,7 +189,7 @@ def main():
                     if op.kind == _lib.AF_OP_STEM_POOL:          # only the pooled tensor is written
                         mm = cd.n * cd.to * ((cd.ho - 1) // 2 + 1) * ((cd.wo - 1) // 2 + 1)
                     elif cd.tpool:
-                        mm //= 2
+                        mm //= (4 if cd.tpool == 2 else 2)
                     eng_bytes[i] = es * (cd.n * cd.t * cd.h * cd.w * cd.cin + mm * cd.cout
                                          + (cd.n * cd.to * cd.ho * cd.wo * cd.cout if op.residual else 0)
                                          + cd.cout * cd.cin * cd.kt * cd.kh * cd.kw)

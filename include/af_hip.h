@@ -57,7 +57,10 @@ typedef struct af_conv_desc {
     int32_t dtype;                  /* af_dtype of in / weights / residual / out */
     int32_t tpool;                  /* 1: also apply MaxPool3d([2,1,1],stride [2,1,1]) (pathway0_pool,
                                        video_model_builder.py:474-480) to the result: out is then
-                                       [n][to/2][ho][wo][cout]; to must be even (af_conv3d_bn_act only) */
+                                       [n][to/2][ho][wo][cout]; to must be even (af_conv3d_bn_act only)
+                                       2: also apply MaxPool3d((1,2,2)) (what FTCN-TT's temporal_only_conv puts
+                                       after the BN of a conv that lost its stride 2): out is [n][to][ho/2][wo/2][cout];
+                                       ho, wo even, no residual (the ReLU, if any, commutes with the max) */
 } af_conv_desc;
 
 typedef struct af_pool_desc {

@@ -38,7 +38,8 @@ struct ConvArgs {
     int To, Ho, Wo;
     int relu, out_ld;
     int ring;           // LDS ring slots used by the lean K loop: 3, or 2 (mid-K HBM-bound layers: 2 workgroups per CU)
-    int tpool;          // fuse MaxPool3d([2,1,1],[2,1,1]) over output frame pairs into the epilogue
+    int tpool;          // 1: fuse MaxPool3d([2,1,1],[2,1,1]) over output frame pairs into the epilogue;
+                        // 2: fuse MaxPool3d([1,2,2],[1,2,2]) over 2x2 output pixels (FTCN-TT's replaced strides)
     long long M;        // N*To*Ho*Wo
     int tiles_n;        // Cout / BN
     int kpt;            // K-steps per tap = Cin / BK
@@ -96,12 +97,15 @@ __global__ __launch_bounds__(WN * WM * KS * 64, MINW) void conv_igemm_kernel(con
     auto row_offsets = [&](long long m, long long& off1, long long& off2, unsigned& mask) {
         // tile row -> output position.  With the temporal pool fused, rows are ordered (n, to/2, ho, wo, to%2):
         // the two frames a pool window spans are ADJACENT rows of the tile (the epilogue takes their max)
-        const long long mq = a.tpool ? (m >> 1) : m;
-        int wo = (int)(mq % a.Wo); long long t1 = mq / a.Wo;
-        int ho = (int)(t1 % a.Ho); long long t2 = t1 / a.Ho;
-        const int tdiv = a.tpool ? (a.To >> 1) : a.To;
+        // (spatial 2x2 pool fused: rows are ordered (n, to, ho/2, wo/2, dy, dx) - a window = 4 adjacent rows)
+        const long long mq = a.tpool == 2 ? (m >> 2) : a.tpool ? (m >> 1) : m;
+        const int wdiv = a.tpool == 2 ? (a.Wo >> 1) : a.Wo, hdiv = a.tpool == 2 ? (a.Ho >> 1) : a.Ho;
+        int wo = (int)(mq % wdiv); long long t1 = mq / wdiv;
+        int ho = (int)(t1 % hdiv); long long t2 = t1 / hdiv;
+        const int tdiv = a.tpool == 1 ? (a.To >> 1) : a.To;
         int to = (int)(t2 % tdiv); long long n = t2 / tdiv;
-        if (a.tpool) to = 2 * to + (int)(m & 1);
+        if (a.tpool == 1) to = 2 * to + (int)(m & 1);
+        if (a.tpool == 2) { ho = 2 * ho + (int)((m >> 1) & 1); wo = 2 * wo + (int)(m & 1); }
         const int ti0 = to * a.st - a.pt, hi0 = ho * a.sh - a.ph, wi0 = wo * a.sw - a.pw;
         off1 = ((((n * a.T + ti0) * a.H + hi0) * a.W + wi0) * a.Cin) * ES;
         off2 = DUAL ? ((((n * a.T2 + to * a.st2) * a.H2 + ho * a.sh2) * a.W2 + wo * a.sw2) * a.Cin2) * ES : 0;
@@ -386,7 +390,35 @@ __global__ __launch_bounds__(WN * WM * KS * 64, MINW) void conv_igemm_kernel(con
                 *reinterpret_cast<f32x4*>(patch + (j * 16 + frow) * PROW + chl) = acc[i][hf * TMH + j] * sc + sf;
         }
         __builtin_amdgcn_wave_barrier();               // same-wave LDS ops complete in order; keep the order
-        if (a.tpool) {
+        if (a.tpool == 2) {
+            // rows 4r .. 4r+3 = the 2x2 window of one pooled pixel: ReLU each, then the max -> pooled row (no residual)
+            constexpr int QR = PROWS / 4;               // pooled rows in the patch (may be fewer than a wave-instruction covers)
+#pragma unroll
+            for (int it = 0; it < (QR + RPI - 1) / RPI; ++it) {
+                const bool live = it * RPI + rr < QR;
+                const int prow = live ? it * RPI + rr : 0;
+                const long long m = m0 + wm * WTM + hf * PROWS + 4 * prow;      // first row of the window
+                float v[EPC];
+#pragma unroll
+                for (int p4 = 0; p4 < 4; ++p4)
+#pragma unroll
+                    for (int e = 0; e < EPC; e += 4) {
+                        const f32x4 t = *reinterpret_cast<const f32x4*>(patch + (4 * prow + p4) * PROW + cc + e);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float x = a.relu ? (t[q] != t[q] ? t[q] : fmaxf(t[q], 0.f)) : t[q];
+                            v[e + q] = (p4 == 0 || x > v[e + q] || x != x) ? x : v[e + q];   // NaN propagates like ATen's max_pool
+                        }
+                    }
+                if (live && m < a.M && ch0 < a.Cout) {
+                    uint4 o;
+                    typename E::type* oe = reinterpret_cast<typename E::type*>(&o);
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) oe[e] = E::from_f32(v[e]);
+                    __builtin_nontemporal_store(__builtin_bit_cast(u32x4, o), reinterpret_cast<u32x4*>(a.out + ((m >> 2) * a.out_ld + ch0) * ES));
+                }
+            }
+        } else if (a.tpool) {
             // rows (2r, 2r+1) = frames (2j, 2j+1) of one pixel: residual add + ReLU each, then the max -> pooled row
 #pragma unroll
             for (int it = 0; it < PROWS / (2 * RPI); ++it) {
@@ -496,10 +528,11 @@ static const char* const kVariantNames[] = {"conv_igemm<BN=128,BM=256>", "conv_i
                                             "conv_igemm<BN=256,BM=256>", "conv_igemm<BN=128,BM=512>",
                                             "conv311_c64<time-tiled, taps share one LDS image>"};
 
-static int pick_variant(int cout, int cin, int taps, int dtype, long long M, int cin2 = 0) {
+static int pick_variant(int cout, int cin, int taps, int dtype, long long M, int cin2 = 0, int pooled = 0) {
     const int ksteps = (taps * cin + cin2) / (dtype == AF_F32 ? 32 : 64);
     const bool wide = cout % 128 == 0, short_k = ksteps <= 3;
-    if (cout % 256 == 0 && !cin2 && ksteps >= 9) {
+    // (with the 2x2 pool fused only a quarter of the output is written: such a layer is MFMA-bound from 4 K-steps on)
+    if (cout % 256 == 0 && !cin2 && ksteps >= (pooled == 2 ? 4 : 9)) {
         // 256x256 tiles (128x64 per wave) move a third less L2 -> LDS traffic per MAC, which is what bounds the
         // 128x256 tile; a layer is as slow as its last round of workgroups, so compare whole rounds on the 256 CUs
         // (measured: one 256x256 tile takes 1.63x the time of a 128x256 tile)
@@ -527,7 +560,7 @@ static int dispatch(ConvArgs& a, hipStream_t stream) {
     a.kpt2 = a.in2 ? (a.Cin2 + BK - 1) / BK : 0;
     a.Cin2P = a.kpt2 * BK;
     a.CoutP = (a.Cout + 63) / 64 * 64;
-    const int v = pick_variant(a.CoutP, a.CinP, a.kt * a.kh * a.kw, DT, a.M, a.in2 ? a.Cin2P : 0);
+    const int v = pick_variant(a.CoutP, a.CinP, a.kt * a.kh * a.kw, DT, a.M, a.in2 ? a.Cin2P : 0, a.tpool);
     a.tiles_n = a.CoutP / (v == VAR_256x256 ? 256 : (v == VAR_128x256 || v == VAR_128x512 || v == VAR_128x128 || v == VAR_128x128_R2) ? 128 : 64);
     a.ring = v == VAR_128x128_R2 ? 2 : 3;
     if (a.in2) {                                 // projection blocks (64-wide tiles: SlowFast's Fast pathway)
@@ -558,7 +591,7 @@ extern "C" int af_conv_variant(const af_conv_desc* d, const af_conv_desc* d2) {
     if (!d2 && af::conv311_applies(d, nullptr, 0)) return af::VAR_C311;
     const int bk = d->dtype == AF_F32 ? 32 : 64;
     return af::pick_variant((d->cout + 63) / 64 * 64, (d->cin + bk - 1) / bk * bk, d->kt * d->kh * d->kw, d->dtype,
-                            (long long)d->n * d->to * d->ho * d->wo, d2 ? (d2->cin + bk - 1) / bk * bk : 0);
+                            (long long)d->n * d->to * d->ho * d->wo, d2 ? (d2->cin + bk - 1) / bk * bk : 0, d->tpool);
 }
 
 extern "C" const char* af_conv_variant_name(int variant) {
@@ -606,8 +639,11 @@ static int conv_common(const af_conv_desc* d, const void* in, const void* w_pack
     a.kt = d->kt; a.kh = d->kh; a.kw = d->kw; a.st = d->st; a.sh = d->sh; a.sw = d->sw;
     a.pt = d->pt; a.ph = d->ph; a.pw = d->pw; a.To = to; a.Ho = ho; a.Wo = wo;
     a.relu = d->relu; a.out_ld = out_ld;
-    a.tpool = d->tpool ? 1 : 0;
-    AF_REQUIRE(!a.tpool || (to % 2 == 0), "conv: fused temporal pool needs an even number of output frames (%d)", to);
+    AF_REQUIRE(d->tpool >= 0 && d->tpool <= 2, "conv: tpool must be 0, 1 (temporal pairs) or 2 (2x2 pixels)");
+    a.tpool = d->tpool;
+    AF_REQUIRE(a.tpool != 1 || (to % 2 == 0), "conv: fused temporal pool needs an even number of output frames (%d)", to);
+    AF_REQUIRE(a.tpool != 2 || (ho % 2 == 0 && wo % 2 == 0 && !residual && !d2),
+               "conv: the fused 2x2 pool needs even output height / width (%d x %d), no residual and no second segment", ho, wo);
     a.M = (long long)d->n * to * ho * wo;
     a.in2 = nullptr; a.w2 = (const char*)w_packed; a.T2 = a.H2 = a.W2 = 1; a.Cin2 = a.Cin2P = bk; a.st2 = a.sh2 = a.sw2 = 1; a.kpt2 = 0;
     if (d2) {

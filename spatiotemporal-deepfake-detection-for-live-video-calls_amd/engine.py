@@ -167,23 +167,31 @@ class _Plan:
             da = blk.a.out_dims(*d)
             self.add(kind="conv", cv=blk.a, din=d, dout=da, src=cur, dst=a_buf); self.need(a_buf, da, blk.a.cout)
             db = blk.b.out_dims(*da)
-            self.add(kind="conv", cv=blk.b, din=da, dout=db, src=a_buf, dst=b_buf); self.need(b_buf, db, blk.b.cout)
             c_src, res_src = b_buf, cur
-            if blk.b.pool_after_bn is not None:
-                # FTCN: conv -> BN -> MaxPool3d((1,2,2)) -> ReLU; the conv launch applies BN + ReLU (max and ReLU
-                # commute), the pool is its own launch into the (now free) a buffer
-                pb = blk.b.pool_after_bn
+            pb = blk.b.pool_after_bn
+            if pb is not None and _is_pool(pb, (1, 2, 2), (1, 2, 2), (0, 0, 0)) and db[1] % 2 == 0 and db[2] % 2 == 0:
+                # FTCN: conv -> BN -> MaxPool3d((1,2,2)) -> ReLU in one launch (max and ReLU commute): the conv's tile
+                # rows are ordered so that a 2x2 window is 4 adjacent rows and the epilogue stores their max
                 dbp = _pool_out(db, pb)
-                self.add(kind="pool", pool=pb, ch=blk.b.cout, din=db, dout=dbp, src=b_buf, dst=a_buf)
-                self.need(a_buf, dbp, blk.b.cout)
-                db, c_src = dbp, a_buf
+                self.add(kind="conv", cv=blk.b, din=da, dout=db, src=a_buf, dst=b_buf, tpool=2); self.need(b_buf, dbp, blk.b.cout)
+                db = dbp
+            else:
+                self.add(kind="conv", cv=blk.b, din=da, dout=db, src=a_buf, dst=b_buf); self.need(b_buf, db, blk.b.cout)
+                if pb is not None:       # odd sizes / other pool shapes: the pool as its own launch into the free a buffer
+                    dbp = _pool_out(db, pb)
+                    self.add(kind="pool", pool=pb, ch=blk.b.cout, din=db, dout=dbp, src=b_buf, dst=a_buf)
+                    self.need(a_buf, dbp, blk.b.cout)
+                    db, c_src = dbp, a_buf
             if blk.branch1 is not None and blk.branch1.pool_after_bn is not None:
                 # pooled projection shortcut: conv + BN, pool, then it is the residual of the c conv
                 p1 = blk.branch1.pool_after_bn
                 d1 = blk.branch1.out_dims(*d)
                 d1p = _pool_out(d1, p1)
-                self.add(kind="conv", cv=blk.branch1, din=d, dout=d1, src=cur, dst="R0"); self.need("R0", d1, blk.branch1.cout)
-                self.add(kind="pool", pool=p1, ch=blk.branch1.cout, din=d1, dout=d1p, src="R0", dst="R1")
+                if _is_pool(p1, (1, 2, 2), (1, 2, 2), (0, 0, 0)) and d1[1] % 2 == 0 and d1[2] % 2 == 0:
+                    self.add(kind="conv", cv=blk.branch1, din=d, dout=d1, src=cur, dst="R1", tpool=2)
+                else:
+                    self.add(kind="conv", cv=blk.branch1, din=d, dout=d1, src=cur, dst="R0"); self.need("R0", d1, blk.branch1.cout)
+                    self.add(kind="pool", pool=p1, ch=blk.branch1.cout, din=d1, dout=d1p, src="R0", dst="R1")
                 self.need("R1", d1p, blk.branch1.cout)
                 res_src = "R1"
             dc = blk.c.out_dims(*db)
@@ -386,7 +394,7 @@ class Engine:
                 # a, b, stems and laterals carry their own ReLU; c (final_bn) takes the block's add + ReLU; the
                 # projection shortcut has neither (resnet_helper.py:311-326, 438-444; video_model_builder.py:136-143)
                 fill_conv(op.conv, cv, e["din"], e["dout"], cv.relu or cv.final_bn)
-                op.conv.tpool = 1 if e.get("tpool") else 0
+                op.conv.tpool = int(e.get("tpool") or 0)
                 op.weight = weights.w[cv.conv].data_ptr()
                 op.scale = weights.scale[cv.conv].data_ptr()
                 op.shift = weights.shift[cv.conv].data_ptr()
@@ -600,7 +608,8 @@ class Engine:
             shape = (op.conv.n, op.conv.to, (op.conv.ho - 1) // 2 + 1, (op.conv.wo - 1) // 2 + 1, op.conv.cout)
         elif op.kind in (_lib.AF_OP_STEM, _lib.AF_OP_CONV, _lib.AF_OP_CONV_DUAL, _lib.AF_OP_TSTEM):
             ld = op.out_ld or op.conv.cout
-            shape = (op.conv.n, op.conv.to // 2 if op.conv.tpool else op.conv.to, op.conv.ho, op.conv.wo, ld)
+            q = 2 if op.conv.tpool == 2 else 1
+            shape = (op.conv.n, op.conv.to // 2 if op.conv.tpool == 1 else op.conv.to, op.conv.ho // q, op.conv.wo // q, ld)
         elif op.kind == _lib.AF_OP_MAXPOOL:
             shape = (op.pool.n, op.pool.to, op.pool.ho, op.pool.wo, op.pool.out_ld or op.pool.c)
         else:

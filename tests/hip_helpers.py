@@ -60,7 +60,8 @@ def conv_bn_act(x_ndhwc, w_oidhw, scale, shift, stride, pad, relu, dtype, residu
     packed = torch.empty(nbytes // (4 if dtype == "f32" else 2), dtype=TORCH_DT[dtype], device="cuda")
     L.check(L.lib.af_pack_conv_weight(_p(wsrc), cout, cin, kt, kh, kw, code, _p(packed), _stream()), "pack_conv_weight")
     if out is None:
-        out = torch.empty((n, d.to // 2 if tpool else d.to, d.ho, d.wo, cout), dtype=TORCH_DT[dtype], device="cuda")
+        q = 2 if int(tpool) == 2 else 1
+        out = torch.empty((n, d.to // 2 if int(tpool) == 1 else d.to, d.ho // q, d.wo // q, cout), dtype=TORCH_DT[dtype], device="cuda")
     L.check(L.lib.af_conv3d_bn_act(C.byref(d), _p(x_ndhwc), _p(packed), _p(scale), _p(shift), _p(residual), _p(out),
                                    out_ld, _stream()), "conv3d_bn_act")
     return out

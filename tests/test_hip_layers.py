@@ -228,6 +228,31 @@ def test_conv_with_fused_temporal_maxpool(dtype, cin, cout, dims):
     assert (got - want).abs().max().item() <= tol * want.abs().max().item()
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cin,cout,dims,relu", [(128, 128, (2, 3, 8, 10), True),       # pooled `b` conv (64x128 tile: 4 pooled rows per patch)
+                                                (256, 512, (1, 4, 12, 6), False),      # pooled projection shortcut
+                                                (64, 256, (1, 16, 56, 56), True)])     # 256x256 tile
+def test_conv_with_fused_2x2_maxpool(dtype, cin, cout, dims, relu):
+    """FTCN-TT: conv -> BN -> MaxPool3d((1,2,2)) [-> ReLU] (i3d_temporal_var_fix_dropout_tt_cfg.py:207-288) in one launch."""
+    seed = 777 + cout
+    lay = [("w.weight", (cout, cin, 1, 1, 1), "float32"), ("bn.weight", (cout,), "float32"), ("bn.bias", (cout,), "float32"),
+           ("bn.running_mean", (cout,), "float32"), ("bn.running_var", (cout,), "float32")]
+    sd = synth.fill_layout(lay, seed)
+    x = synth.synthetic_tensor((dims[0], cin) + dims[1:], seed)
+    if dtype != "f32":
+        x = x.to(hh.TORCH_DT[dtype]).float()
+        sd["w.weight"] = sd["w.weight"].to(hh.TORCH_DT[dtype]).float()
+    y = oracle.conv_bn_act(x.double(), sd["w.weight"].double(), {k: v.double() for k, v in sd.items()}, "bn", (1, 1, 1), (0, 0, 0), False)
+    want = F.max_pool3d(y, (1, 2, 2))
+    if relu:
+        want = F.relu(want)
+    got = hh.conv_bn_act(hh.to_ndhwc(x, dtype), sd["w.weight"], *hh.fold_bn(sd, "bn"), (1, 1, 1), (0, 0, 0), relu, dtype, tpool=2)
+    got = hh.to_ncdhw(got).double()
+    assert got.shape == want.shape
+    tol = {"f32": 2e-6, "f16": 1.5e-3, "bf16": 1.2e-2}[dtype]
+    assert (got - want).abs().max().item() <= tol * (want.abs().max().item() + 1e-9)
+
+
 def test_conv_out_ld_writes_into_concat_buffer():
     """FuseFastToSlow concatenates by channel: the conv writes at a channel offset of a wider tensor."""
     dtype = "f32"
