@@ -399,6 +399,51 @@ def gen_ftcn():
     np.savez_compressed(os.path.join(GOLD, "f6_ftcn_stages.npz"), **f6)
 
 
+def gen_dualrun():
+    """F7: the reference's dualrun ``DualEncoderAU_LMK`` (dualrun/model/dual_encoder.py), built like dualrun/cli/run.py:175-187
+    with checkpoints/test7/args.json (d_model 256, 4 layers, 4 heads, ff_dim 768, T 8).  The module is pure torch and is
+    imported straight from its file (its package name ``model`` would collide with altfreezing's)."""
+    import importlib.util
+    from af_mi355x import dualrun
+    path = os.path.join(ref_import.REFERENCE_ROOT, "dualrun", "model", "dual_encoder.py")
+    spec_ = importlib.util.spec_from_file_location("ref_dual_encoder", path)
+    mod = importlib.util.module_from_spec(spec_)
+    spec_.loader.exec_module(mod)
+    sp = dualrun.DualSpec()
+    net = mod.DualEncoderAU_LMK(au_dim=sp.au_dim, lmk_dim=sp.lmk_dim, d_model=sp.d_model, depth=sp.depth, heads=sp.heads,
+                                mlp_ratio=float(sp.ff) / sp.d_model, dropout=0.15, pool_tau=sp.pool_tau).eval()
+    lay = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
+    assert lay == [(k, tuple(sh)) for k, sh in dualrun.dual_state_dict_layout(sp)], "product dualrun table disagrees with the reference"
+    sd = dualrun.dual_synthetic_state_dict(sp, seed=WEIGHT_SEED)
+    net.load_state_dict(sd)
+    out = {}
+    for tag, batch, frames, ragged in (("b6_t8", 6, 8, True), ("b3_t8_full", 3, 8, False), ("b2_t5", 2, 5, True)):
+        A, L, lengths = dualrun.synthetic_dual_inputs(batch, sp, frames=frames, seed=CLIP_SEED)
+        if not ragged:
+            lengths = None
+        if tag == "b2_t5":
+            lengths = torch.tensor([5, 0], dtype=torch.int32)          # a clip with no valid frame (keeps frame 0)
+        with torch.no_grad():
+            o32 = net(A, L, lengths, return_z=True)
+        net.double()
+        with torch.no_grad():
+            o64 = net(A.double(), L.double(), lengths, return_z=True)
+        net.float()
+        out[tag + "_lengths"] = np.array([-1]) if lengths is None else lengths.numpy().astype(np.int64)
+        out[tag + "_logits_f32"] = o32["bin_logits"].numpy()
+        out[tag + "_logits_f64"] = o64["bin_logits"].numpy()
+        out[tag + "_z_f32"] = o32["z"].numpy()
+        print("F7 dualrun", tag, "logits", o32["bin_logits"].numpy().round(5).tolist())
+    with open(os.path.join(GOLD, "f7_dualrun.json"), "w") as f:
+        json.dump({"source": "reference dualrun/model/dual_encoder.py DualEncoderAU_LMK (au 36, lmk 132, d_model 256, depth 4, "
+                             "heads 4, mlp_ratio 3.0, pool_tau 1.0), eval, PyTorch CPU, weights dual_synthetic_state_dict(seed), "
+                             "inputs synthetic_dual_inputs(seed)",
+                   "num_keys": len(lay), "num_params": int(sum(p.numel() for p in net.parameters())),
+                   "weights_seed": WEIGHT_SEED, "inputs_seed": CLIP_SEED,
+                   "weights_sha256": synth.state_dict_sha256(sd)}, f, indent=1)
+    np.savez_compressed(os.path.join(GOLD, "f7_dualrun.npz"), **out)
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.manual_seed(0)
@@ -409,10 +454,15 @@ def main():
     gen_f4(clf)
     gen_f1_f2(clf)
     gen_slowfast()
+    gen_dualrun()
 
 
 if __name__ == "__main__":
-    if "--ftcn" in sys.argv:
+    if "--dualrun" in sys.argv:
+        os.makedirs(GOLD, exist_ok=True)
+        torch.set_num_threads(8)
+        gen_dualrun()
+    elif "--ftcn" in sys.argv:
         os.makedirs(GOLD, exist_ok=True)
         torch.manual_seed(0)
         torch.set_num_threads(8)

@@ -1,0 +1,318 @@
+// dualrun AU / landmark dual encoder (reference dualrun/model/dual_encoder.py:53-198), fp32.
+//
+// A clip is T <= 16 frames of a few dozen features; the whole BranchEncoder (Linear + LayerNorm, difference /
+// high-pass mix, dilated depthwise pyramid + pointwise conv + GELU, positions, `depth` pre-norm transformer layers,
+// attention pooling) is ONE launch: a 256-thread workgroup per clip keeps every activation in LDS ([T][256] rows,
+// [T][768] for qkv / the MLP hidden) and streams the 2.4 M weights of the branch from L2 in a flat, pre-transposed
+// image (W^T, so that consecutive threads read consecutive output columns: coalesced, each weight read once per
+// workgroup and reused for all T rows from registers).  One thread = one channel of d_model = 256 for the
+// channel-wise steps.  The 16 clips of a batch are 16 workgroups reading the same weights (L2 hits).
+// The classification head (LayerNorm -> Linear -> GELU -> Linear on the concatenated clip vectors) is a second
+// one-workgroup-per-clip kernel.
+#include "af_common.h"
+
+namespace af {
+
+constexpr int DUAL_D = 256;            // d_model the kernels are built for (= threads per workgroup)
+constexpr int DUAL_MAXT = 16;
+constexpr int DUAL_MAXW = 768;         // widest row kept in LDS (3 * d_model, dim_feedforward)
+
+struct DualArgs {
+    const float* x;        // [clips][T][din]
+    const int* lengths;    // [clips] valid frames, or null
+    const float* w;        // flat weight image (layout: dual_branch_weight_floats)
+    const float* pe;       // [T][D] sinusoidal positions
+    float* z;              // clip vectors: z[clip * z_ld + 0..D)
+    int T, din, depth, heads, ff, z_ld;
+    float inv_tau;
+};
+
+__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f)); }
+
+// y[t][n] = act(bias[n] + sum_k x[t][k] * Wt[k][n]) (+ res[t][n]);  x, y, res in LDS, Wt / bias in global memory
+template <int TT>
+__device__ __forceinline__ void linear_rows(const float* xs, int ldx, int K, const float* Wt, const float* bias, int N,
+                                            float* ys, int ldy, int T, bool gelu, const float* res, int ldr) {
+    for (int n = threadIdx.x; n < N; n += DUAL_D) {
+        float acc[TT];
+        const float b = bias[n];
+#pragma unroll
+        for (int t = 0; t < TT; ++t) acc[t] = b;
+        for (int k = 0; k < K; k += 4) {                                                // K % 4 == 0 (host-checked)
+            const float w0 = Wt[(long long)k * N + n], w1 = Wt[(long long)(k + 1) * N + n],
+                        w2 = Wt[(long long)(k + 2) * N + n], w3 = Wt[(long long)(k + 3) * N + n];
+#pragma unroll
+            for (int t = 0; t < TT; ++t) {                                               // rows >= T hold zeros
+                const float4 xv = *reinterpret_cast<const float4*>(xs + t * ldx + k);    // one broadcast ds_read_b128
+                acc[t] = fmaf(xv.w, w3, fmaf(xv.z, w2, fmaf(xv.y, w1, fmaf(xv.x, w0, acc[t]))));
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < TT; ++t)
+            if (t < T) {
+                float v = gelu ? gelu_erf(acc[t]) : acc[t];
+                if (res) v += res[t * ldr + n];
+                ys[t * ldy + n] = v;
+            }
+    }
+}
+
+// nn.LayerNorm(256) over the rows of an LDS matrix; wave w takes rows w, w + 4, ...
+__device__ __forceinline__ void layernorm_rows(const float* xs, float* ys, int T, const float* gamma, const float* beta) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int t = wave; t < T; t += DUAL_D / 64) {
+        float v[4], s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[i] = xs[t * DUAL_D + lane + 64 * i]; s += v[i]; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        const float mean = s * (1.f / DUAL_D);
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const float d = v[i] - mean; q += d * d; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+        const float rstd = rsqrtf(q * (1.f / DUAL_D) + 1e-5f);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = lane + 64 * i;
+            ys[t * DUAL_D + c] = (v[i] - mean) * rstd * gamma[c] + beta[c];
+        }
+    }
+}
+
+template <int TT>
+__global__ __launch_bounds__(DUAL_D) void dual_branch_kernel(const DualArgs a) {
+    extern __shared__ float sm[];
+    constexpr int D = DUAL_D;
+    float* h = sm;                          // [TT][D]   the residual stream
+    float* y = h + TT * D;                  // [TT][D]   LayerNorm output / scratch
+    float* o = y + TT * D;                  // [TT][D]   attention output / input rows
+    float* big = o + TT * D;                // [TT][768] qkv, MLP hidden
+    float* sc = big + TT * DUAL_MAXW;       // [heads][TT][TT] attention probabilities; pooling weights
+    const int tid = threadIdx.x, clip = blockIdx.x, T = a.T;
+    int len = a.lengths ? a.lengths[clip] : T;
+    len = len < 1 ? 1 : (len > T ? T : len);                     // a clip without valid frames keeps frame 0 (:162-166)
+
+    // zero the row buffers once: rows >= T feed the (unrolled) row loops with zeros
+    for (int i = tid; i < 3 * TT * D + TT * DUAL_MAXW; i += D) sm[i] = 0.f;
+    __syncthreads();
+    const float* xg = a.x + (long long)clip * T * a.din;
+    for (int i = tid; i < T * a.din; i += D) o[(i / a.din) * D + (i % a.din)] = xg[i];          // din <= 256 (host-checked)
+    __syncthreads();
+
+    const float* w = a.w;
+    // ---- h = ln_in(proj(x))                                                     (dual_encoder.py:75)
+    linear_rows<TT>(o, D, a.din, w, w + (long long)a.din * D, D, y, D, T, false, nullptr, 0);
+    w += (long long)a.din * D + D;
+    __syncthreads();
+    layernorm_rows(y, h, T, w, w + D);
+    w += 2 * D;
+    __syncthreads();
+    // ---- first difference + moving-average high-pass mix, depthwise dilated pyramid (thread = channel)   (:77-91)
+    {
+        const int c = tid;
+        float v[TT], m[TT];
+#pragma unroll
+        for (int t = 0; t < TT; ++t) v[t] = h[t * D + c];                       // zeros beyond T = the convs' zero padding
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            float ma = 0.f;                                                      // avg_pool1d(5, pad 2), pad counted
+#pragma unroll
+            for (int j = -2; j <= 2; ++j) ma += (t + j >= 0 && t + j < TT) ? v[t + j] : 0.f;
+            const float delta = t == 0 ? 0.f : v[t] - v[t - 1];
+            m[t] = v[t] + 0.5f * delta + 0.5f * (v[t] - ma * 0.2f);
+        }
+#pragma unroll
+        for (int t = 0; t < TT; ++t) if (t >= T) m[t] = 0.f;                    // the sequence ends at T (zero padding)
+        float p[TT];
+#pragma unroll
+        for (int t = 0; t < TT; ++t) p[t] = m[t];                                // + skip (:89)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int d = 1 << i;
+            const float w0 = w[c * 3 + 0], w1 = w[c * 3 + 1], w2 = w[c * 3 + 2], b = w[3 * D + c];
+#pragma unroll
+            for (int t = 0; t < TT; ++t)
+                p[t] += b + (t - d >= 0 ? w0 * m[t - d] : 0.f) + w1 * m[t] + (t + d < TT ? w2 * m[t + d] : 0.f);
+            w += 4 * D;
+        }
+#pragma unroll
+        for (int t = 0; t < TT; ++t) y[t * D + c] = t < T ? p[t] : 0.f;
+    }
+    __syncthreads();
+    // ---- pointwise conv (a Linear over channels) + GELU, + positions                                       (:90-94)
+    linear_rows<TT>(y, D, D, w, w + D * D, D, h, D, T, true, a.pe, D);
+    w += D * D + D;
+    __syncthreads();
+
+    const int dh = D / a.heads;
+    const float qscale = rsqrtf((float)dh);
+    for (int l = 0; l < a.depth; ++l) {
+        // ---- x = x + self_attn(norm1(x))       (nn.TransformerEncoderLayer, norm_first; key padding mask on the keys)
+        layernorm_rows(h, y, T, w, w + D);
+        w += 2 * D;
+        __syncthreads();
+        linear_rows<TT>(y, D, D, w, w + 3 * D * D, 3 * D, big, DUAL_MAXW, T, false, nullptr, 0);
+        w += 3 * D * D + 3 * D;
+        __syncthreads();
+        for (int i = tid; i < a.heads * T * T; i += D) {
+            const int s = i % T, t = (i / T) % T, hd = i / (T * T);
+            float dot = 0.f;
+            const float* q = big + t * DUAL_MAXW + hd * dh;
+            const float* k = big + s * DUAL_MAXW + D + hd * dh;
+            for (int d = 0; d < dh; ++d) dot = fmaf(q[d], k[d], dot);
+            sc[(hd * TT + t) * TT + s] = s < len ? dot * qscale : -INFINITY;
+        }
+        __syncthreads();
+        for (int i = tid; i < a.heads * T; i += D) {
+            float* row = sc + (i / T * TT + i % T) * TT;
+            float mx = -INFINITY;
+            for (int s = 0; s < T; ++s) mx = fmaxf(mx, row[s]);
+            float zs = 0.f;
+            for (int s = 0; s < T; ++s) { const float e = expf(row[s] - mx); row[s] = e; zs += e; }
+            const float inv = 1.f / zs;
+            for (int s = 0; s < T; ++s) row[s] *= inv;
+        }
+        __syncthreads();
+        {
+            const int c = tid, hd = c / dh;
+            for (int t = 0; t < T; ++t) {
+                float acc = 0.f;
+                for (int s = 0; s < T; ++s) acc = fmaf(sc[(hd * TT + t) * TT + s], big[s * DUAL_MAXW + 2 * D + c], acc);
+                o[t * D + c] = acc;
+            }
+        }
+        __syncthreads();
+        linear_rows<TT>(o, D, D, w, w + D * D, D, h, D, T, false, h, D);          // out_proj + residual (in place: one
+        w += D * D + D;                                                           // thread owns a column of h)
+        __syncthreads();
+        // ---- x = x + linear2(gelu(linear1(norm2(x))))
+        layernorm_rows(h, y, T, w, w + D);
+        w += 2 * D;
+        __syncthreads();
+        linear_rows<TT>(y, D, D, w, w + (long long)D * a.ff, a.ff, big, DUAL_MAXW, T, true, nullptr, 0);
+        w += (long long)D * a.ff + a.ff;
+        __syncthreads();
+        linear_rows<TT>(big, DUAL_MAXW, a.ff, w, w + (long long)a.ff * D, D, h, D, T, false, h, D);
+        w += (long long)a.ff * D + D;
+        __syncthreads();
+    }
+    // ---- attention pooling: softmax_t(h v / tau) over the valid frames                                     (:30-47)
+    {
+        const int lane = tid & 63, wave = tid >> 6;
+        for (int t = wave; t < T; t += D / 64) {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s = fmaf(h[t * D + lane + 64 * i], w[lane + 64 * i], s);
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+            if (lane == 0) sc[t] = t < len ? s * a.inv_tau : -3.402823466e38f;        // masked_fill(finfo.min)
+        }
+    }
+    __syncthreads();
+    {
+        float mx = -INFINITY;
+        for (int t = 0; t < T; ++t) mx = fmaxf(mx, sc[t]);
+        float zs = 0.f, acc = 0.f;
+        for (int t = 0; t < T; ++t) { const float e = expf(sc[t] - mx); zs += e; acc = fmaf(e, h[t * D + tid], acc); }
+        a.z[(long long)clip * a.z_ld + tid] = acc / zs;
+    }
+}
+
+// head: LayerNorm(n) -> Linear(n, n) -> GELU -> Linear(n, 1);  flat weights: gamma, beta, W1^T [n][n], b1, w2, b2
+__global__ __launch_bounds__(256) void dual_head_kernel(const float* z, const float* w, int n, float* logits) {
+    extern __shared__ float sm[];
+    float* x = sm; float* y = sm + n; float* red = y + n;
+    const int tid = threadIdx.x, clip = blockIdx.x;
+    float s = 0.f;
+    for (int i = tid; i < n; i += 256) { x[i] = z[(long long)clip * n + i]; s += x[i]; }
+    red[tid] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+    const float mean = red[0] / n;
+    __syncthreads();
+    float q = 0.f;
+    for (int i = tid; i < n; i += 256) { const float d = x[i] - mean; q += d * d; }
+    red[tid] = q;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+    const float rstd = rsqrtf(red[0] / n + 1e-5f);
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) x[i] = (x[i] - mean) * rstd * w[i] + w[n + i];
+    __syncthreads();
+    const float* W1t = w + 2 * n; const float* b1 = W1t + (long long)n * n; const float* w2 = b1 + n;
+    float part = 0.f;
+    for (int j = tid; j < n; j += 256) {
+        float acc = b1[j];
+        for (int k = 0; k < n; ++k) acc = fmaf(x[k], W1t[(long long)k * n + j], acc);
+        part = fmaf(gelu_erf(acc), w2[j], part);
+    }
+    red[tid] = part;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+    if (tid == 0) logits[clip] = red[0] + w2[n];
+}
+
+__global__ void transpose_f32_kernel(const float* src, int rows, int cols, float* dst) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)rows * cols) return;
+    const int r = (int)(i / cols), c = (int)(i % cols);
+    dst[(long long)c * rows + r] = src[i];
+}
+
+}  // namespace af
+
+extern "C" long long af_dual_branch_weight_floats(int din, int d_model, int depth, int ff) {
+    const long long D = d_model;
+    return (long long)din * D + D + 2 * D + 3 * 4 * D + D * D + D +
+           (long long)depth * (2 * D + 3 * D * D + 3 * D + D * D + D + 2 * D + D * ff + ff + (long long)ff * D + D) + D;
+}
+
+extern "C" int af_transpose_f32(const float* src, int rows, int cols, float* dst, void* stream) {
+    using namespace af;
+    AF_REQUIRE(src && dst && rows > 0 && cols > 0, "transpose: bad argument");
+    const long long n = (long long)rows * cols;
+    hipLaunchKernelGGL(transpose_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, rows, cols, dst);
+    AF_CHECK_LAUNCH("transpose_f32_kernel");
+    return AF_OK;
+}
+
+extern "C" int af_dual_branch_encoder(const float* x, const int* lengths, const float* weights, const float* pe, int clips,
+                                      int frames, int din, int d_model, int depth, int heads, int ff, float pool_tau, float* z,
+                                      int z_ld, void* stream) {
+    using namespace af;
+    AF_REQUIRE(x && weights && pe && z && clips >= 0, "dual_branch_encoder: null argument");
+    AF_REQUIRE(d_model == DUAL_D, "dual_branch_encoder: built for d_model = %d (got %d)", DUAL_D, d_model);
+    AF_REQUIRE(frames >= 1 && frames <= DUAL_MAXT, "dual_branch_encoder: 1..%d frames per clip (got %d)", DUAL_MAXT, frames);
+    AF_REQUIRE(din >= 4 && din <= DUAL_D && din % 4 == 0, "dual_branch_encoder: 4..%d input features, a multiple of 4 (got %d)", DUAL_D, din);
+    AF_REQUIRE(depth >= 0 && heads >= 1 && d_model % heads == 0 && heads * frames * frames <= 4 * DUAL_MAXT * DUAL_MAXT,
+               "dual_branch_encoder: bad depth / heads");
+    AF_REQUIRE(ff >= 4 && ff <= DUAL_MAXW && ff % 4 == 0, "dual_branch_encoder: dim_feedforward 4..%d, a multiple of 4 (got %d)", DUAL_MAXW, ff);
+    AF_REQUIRE(z_ld >= d_model, "dual_branch_encoder: z_ld < d_model");
+    if (clips == 0) return AF_OK;
+    DualArgs a;
+    a.x = x; a.lengths = lengths; a.w = weights; a.pe = pe; a.z = z;
+    a.T = frames; a.din = din; a.depth = depth; a.heads = heads; a.ff = ff; a.z_ld = z_ld;
+    a.inv_tau = 1.0f / (pool_tau > 1e-3f ? pool_tau : 1e-3f);
+    const int tt = frames <= 8 ? 8 : 16;
+    const int hmax = heads > 4 ? heads : 4;
+    const int lds = (3 * tt * DUAL_D + tt * DUAL_MAXW + hmax * tt * tt) * 4;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = tt == 8 ? hipFuncSetAttribute(reinterpret_cast<const void*>(&dual_branch_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)
+                           : hipFuncSetAttribute(reinterpret_cast<const void*>(&dual_branch_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return set_error(AF_ERR_LAUNCH, "dual_branch_encoder: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    if (tt == 8) hipLaunchKernelGGL((dual_branch_kernel<8>), dim3(clips), dim3(DUAL_D), lds, s, a);
+    else hipLaunchKernelGGL((dual_branch_kernel<16>), dim3(clips), dim3(DUAL_D), lds, s, a);
+    AF_CHECK_LAUNCH("dual_branch_kernel");
+    return AF_OK;
+}
+
+extern "C" int af_dual_head(const float* z, const float* weights, int clips, int n, float* logits, void* stream) {
+    using namespace af;
+    AF_REQUIRE(z && weights && logits && clips >= 0 && n >= 1 && n <= 4096, "dual_head: bad argument");
+    if (clips == 0) return AF_OK;
+    hipLaunchKernelGGL(dual_head_kernel, dim3(clips), dim3(256), (2 * n + 256) * 4, (hipStream_t)stream, z, weights, n, logits);
+    AF_CHECK_LAUNCH("dual_head_kernel");
+    return AF_OK;
+}

@@ -136,6 +136,26 @@ def test_ftcn_tt_logits_stages_and_head():
         np.testing.assert_allclose(got, st["%s_val" % name], rtol=1e-4, atol=1e-5)
 
 
+def test_dualrun_oracle_matches_reference():
+    """oracle/dualrun_oracle.py against the reference's DualEncoderAU_LMK (tests/golden/f7_dualrun.*): ragged lengths, no
+    lengths, and a clip without a single valid frame."""
+    import dualrun_oracle
+    from af_mi355x import dualrun
+    g = load_json("f7_dualrun.json")
+    st = load_npz("f7_dualrun.npz")
+    sp = dualrun.DualSpec()
+    sd = dualrun.dual_synthetic_state_dict(sp, seed=g["weights_seed"])
+    assert synth.state_dict_sha256(sd) == g["weights_sha256"] and len(sd) == g["num_keys"] == 136
+    assert sum(v.numel() for v in sd.values()) == g["num_params"] == 5789989
+    for tag, batch, frames in (("b6_t8", 6, 8), ("b3_t8_full", 3, 8), ("b2_t5", 2, 5)):
+        A, L, _ = dualrun.synthetic_dual_inputs(batch, sp, frames=frames, seed=g["inputs_seed"])
+        ln = st[tag + "_lengths"]
+        lengths = None if ln[0] < 0 else torch.from_numpy(ln)
+        logits, z = dualrun_oracle.dual_forward(sd, A, L, lengths, heads=sp.heads, tau=sp.pool_tau)
+        np.testing.assert_allclose(logits.numpy(), st[tag + "_logits_f32"], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(z.numpy(), st[tag + "_z_f32"], rtol=2e-6, atol=5e-6)
+
+
 def test_checkpoint_unwrap_rules():
     base = {"resnet.a": torch.ones(1)}
     assert list(oracle.strip_checkpoint({"state_dict": {"module.resnet.a": 1}})) == ["resnet.a"]
