@@ -72,6 +72,65 @@ def pmc_traffic(kernel_label, dtype):
     return None, None
 
 
+def bench_dualrun(args, rank, world, dev):
+    """SURVEY 8d config C4's extra branch on its own: the dualrun AU / landmark dual encoder (T = 8 frames per clip,
+    d_model 256, 4 layers) on `--batch` clips per GPU; value = clips/s.  Not the BASELINE metric (use --model i3d)."""
+    from af_mi355x import dualrun
+    sp = dualrun.DualSpec()
+    sd = dualrun.dual_synthetic_state_dict(sp, seed=0)
+    net = dualrun.DualEncoderAU_LMK(au_dim=sp.au_dim, lmk_dim=sp.lmk_dim, d_model=sp.d_model, depth=sp.depth, heads=sp.heads,
+                                    mlp_ratio=float(sp.ff) / sp.d_model, pool_tau=sp.pool_tau)
+    net.load_state_dict(sd)
+    net = net.to(dev).eval()
+    B = args.batch
+    A, L, lengths = dualrun.synthetic_dual_inputs(B, sp, frames=8, seed=2026 + rank)
+    Ad, Ld, ld = A.to(dev), L.to(dev), lengths.to(dev)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    with torch.inference_mode():
+        for _ in range(args.warmup):
+            out = net(Ad, Ld, ld)["bin_logits"]
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = net(Ad, Ld, ld)["bin_logits"]
+        fence()
+        dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    line = {"metric": "clips/sec (dualrun AU+LMK encoder, 8 frames)", "value": round(world * B * args.steps / dt, 2), "unit": "clips/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "dualrun DualEncoderAU_LMK forward (AU 36 + LMK 132 features x 8 frames, d_model 256, 4 layers, "
+                                   "4 heads, ff 768), batch=%d clips/GPU, synthetic weights / inputs" % B,
+                       "global_batch": world * B, "parallelism": "dp%d" % world}}
+    if rank == 0 and world == 1 and args.cpu_clips > 0:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import dualrun_oracle
+        torch.set_num_threads(16)
+        dualrun_oracle.dual_forward(sd, A[:1], L[:1], lengths[:1], heads=sp.heads, tau=sp.pool_tau)
+        t0 = time.perf_counter()
+        reps = 20
+        for _ in range(reps):
+            ref, _ = dualrun_oracle.dual_forward(sd, A, L, lengths, heads=sp.heads, tau=sp.pool_tau)
+        tc = (time.perf_counter() - t0) / reps
+        line["cpu_baseline"] = {"value": round(B / tc, 2), "unit": "clips/s", "cores": 16, "kind": "port",
+                                "sample": "%d clips x %d repetitions, PyTorch CPU oracle, 16 threads" % (B, reps)}
+        line["max_abs_logit_err_vs_cpu_fp32"] = float((out.float().cpu() - ref).abs().max())
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -80,7 +139,7 @@ def main():
     ap.add_argument("--batch", type=int, default=16, help="clips per GPU")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--cpu-clips", type=int, default=4, help="clips in the CPU baseline sample (0 = skip)")
-    ap.add_argument("--model", default="i3d", choices=["i3d", "slowfast", "ftcn_tt"],
+    ap.add_argument("--model", default="i3d", choices=["i3d", "slowfast", "ftcn_tt", "dualrun"],
                     help="i3d = the i3d_ori plugin (BASELINE metric); slowfast = the two-pathway SlowFast-R50, ftcn_tt = the "
                          "reference's second plugin (next rows of SURVEY 8f)")
     ap.add_argument("--no-roofline", action="store_true")
@@ -102,6 +161,8 @@ def main():
     torch.cuda.set_device(dev)
     B = args.batch
 
+    if args.model == "dualrun":
+        return bench_dualrun(args, rank, world, dev)
     if args.model == "slowfast":
         from af_mi355x.arch import slowfast_r50_spec
         from af_mi355x.classifier import SlowFast8x8

@@ -198,17 +198,18 @@ int af_gelu(float* x, long long n, void* stream);
 
 /* ---- dualrun AU / landmark dual encoder (reference dualrun/model/dual_encoder.py) --------------------- */
 
-/* BranchEncoder.forward (:73-107) for `clips` clips of `frames` <= 16 frames x `din` features, fp32, one launch:
- * x [clips][frames][din]; lengths [clips] valid frames (NULL: all; 0 counts as 1 like :162-166); pe [frames][d_model]
- * sinusoidal table (:16-23); z[clip * z_ld + 0..d_model) = the attention-pooled clip vector.  `weights` is the flat
- * fp32 image af_dual_branch_weight_floats() sizes: proj W^T, b | ln_in g, b | 3 x (depthwise w [c][3], b) | pointwise
- * W^T, b | per layer: norm1 g, b | in_proj W^T, b | out_proj W^T, b | norm2 g, b | linear1 W^T, b | linear2 W^T, b |
- * pool v   (W^T = [in][out], af_transpose_f32 of the checkpoint's [out][in]). */
+/* BranchEncoder.forward (:73-107) of `branches` modalities (AU, landmarks, ...) for `clips` clips of `frames` <= 16
+ * frames, fp32, ONE launch (grid = clips x branches): x[b] [clips][frames][din[b]]; lengths [clips] valid frames (NULL:
+ * all; 0 counts as 1 like :162-166); pe [frames][d_model] sinusoidal table (:16-23);
+ * z[clip * z_ld + b * d_model + 0..d_model) = the attention-pooled clip vector of branch b (already concatenated).
+ * weights[b] is the flat fp32 image af_dual_branch_weight_floats() sizes: proj W^T, b | ln_in g, b | 3 x (depthwise
+ * w [c][3], b) | pointwise W^T, b | per layer: norm1 g, b | in_proj W^T, b | out_proj W^T, b | norm2 g, b | linear1
+ * W^T, b | linear2 W^T, b | pool v   (W^T = [in][out], af_transpose_f32 of the checkpoint's [out][in]). */
 long long af_dual_branch_weight_floats(int din, int d_model, int depth, int ff);
 int af_transpose_f32(const float* src, int rows, int cols, float* dst, void* stream);
-int af_dual_branch_encoder(const float* x, const int* lengths, const float* weights, const float* pe, int clips, int frames,
-                           int din, int d_model, int depth, int heads, int ff, float pool_tau, float* z, int z_ld,
-                           void* stream);
+int af_dual_branch_encoders(int branches, const float* const* x, const float* const* weights, const int* din,
+                            const int* lengths, const float* pe, int clips, int frames, int d_model, int depth, int heads,
+                            int ff, float pool_tau, float* z, int z_ld, void* stream);
 /* DualEncoderAU_LMK.head (:115-121): LayerNorm(n) -> Linear(n,n) -> GELU -> Linear(n,1) on z [clips][n];
  * weights: gamma, beta, W1^T [n][n], b1, w2 [n], b2. */
 int af_dual_head(const float* z, const float* weights, int clips, int n, float* logits, void* stream);

@@ -77,7 +77,8 @@ ABI = {
     "af_gelu": (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p]),
     "af_dual_branch_weight_floats": (C.c_longlong, [C.c_int] * 4),
     "af_transpose_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
-    "af_dual_branch_encoder": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 7 + [C.c_float, C.c_void_p, C.c_int, C.c_void_p]),
+    "af_dual_branch_encoders": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_void_p,
+                                           C.c_void_p] + [C.c_int] * 6 + [C.c_float, C.c_void_p, C.c_int, C.c_void_p]),
     "af_dual_head": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "af_run_ops": (C.c_int, [C.POINTER(Op), C.c_int, C.c_void_p]),
     "af_run_ops_timed": (C.c_int, [C.POINTER(Op), C.c_int, C.c_void_p, C.POINTER(C.c_float)]),

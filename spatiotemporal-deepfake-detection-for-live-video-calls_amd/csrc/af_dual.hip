@@ -17,13 +17,15 @@ constexpr int DUAL_D = 256;            // d_model the kernels are built for (= t
 constexpr int DUAL_MAXT = 16;
 constexpr int DUAL_MAXW = 768;         // widest row kept in LDS (3 * d_model, dim_feedforward)
 
+constexpr int DUAL_MAXB = 4;           // modalities encoded by one launch (blockIdx.y)
 struct DualArgs {
-    const float* x;        // [clips][T][din]
+    const float* x[DUAL_MAXB];   // [clips][T][din] per branch
+    const float* w[DUAL_MAXB];   // flat weight image per branch (layout: dual_branch_weight_floats)
+    int din[DUAL_MAXB];
     const int* lengths;    // [clips] valid frames, or null
-    const float* w;        // flat weight image (layout: dual_branch_weight_floats)
     const float* pe;       // [T][D] sinusoidal positions
-    float* z;              // clip vectors: z[clip * z_ld + 0..D)
-    int T, din, depth, heads, ff, z_ld;
+    float* z;              // clip vectors: z[clip * z_ld + branch * D + 0..D)
+    int T, depth, heads, ff, z_ld;
     float inv_tau;
 };
 
@@ -38,6 +40,7 @@ __device__ __forceinline__ void linear_rows(const float* xs, int ldx, int K, con
         const float b = bias[n];
 #pragma unroll
         for (int t = 0; t < TT; ++t) acc[t] = b;
+#pragma unroll 4                                                                         // 16 weight loads in flight per thread
         for (int k = 0; k < K; k += 4) {                                                // K % 4 == 0 (host-checked)
             const float w0 = Wt[(long long)k * N + n], w1 = Wt[(long long)(k + 1) * N + n],
                         w2 = Wt[(long long)(k + 2) * N + n], w3 = Wt[(long long)(k + 3) * N + n];
@@ -90,21 +93,22 @@ __global__ __launch_bounds__(DUAL_D) void dual_branch_kernel(const DualArgs a) {
     float* o = y + TT * D;                  // [TT][D]   attention output / input rows
     float* big = o + TT * D;                // [TT][768] qkv, MLP hidden
     float* sc = big + TT * DUAL_MAXW;       // [heads][TT][TT] attention probabilities; pooling weights
-    const int tid = threadIdx.x, clip = blockIdx.x, T = a.T;
+    const int tid = threadIdx.x, clip = blockIdx.x, br = blockIdx.y, T = a.T;
+    const int din = a.din[br];
     int len = a.lengths ? a.lengths[clip] : T;
     len = len < 1 ? 1 : (len > T ? T : len);                     // a clip without valid frames keeps frame 0 (:162-166)
 
     // zero the row buffers once: rows >= T feed the (unrolled) row loops with zeros
     for (int i = tid; i < 3 * TT * D + TT * DUAL_MAXW; i += D) sm[i] = 0.f;
     __syncthreads();
-    const float* xg = a.x + (long long)clip * T * a.din;
-    for (int i = tid; i < T * a.din; i += D) o[(i / a.din) * D + (i % a.din)] = xg[i];          // din <= 256 (host-checked)
+    const float* xg = a.x[br] + (long long)clip * T * din;
+    for (int i = tid; i < T * din; i += D) o[(i / din) * D + (i % din)] = xg[i];                // din <= 256 (host-checked)
     __syncthreads();
 
-    const float* w = a.w;
+    const float* w = a.w[br];
     // ---- h = ln_in(proj(x))                                                     (dual_encoder.py:75)
-    linear_rows<TT>(o, D, a.din, w, w + (long long)a.din * D, D, y, D, T, false, nullptr, 0);
-    w += (long long)a.din * D + D;
+    linear_rows<TT>(o, D, din, w, w + (long long)din * D, D, y, D, T, false, nullptr, 0);
+    w += (long long)din * D + D;
     __syncthreads();
     layernorm_rows(y, h, T, w, w + D);
     w += 2 * D;
@@ -216,7 +220,7 @@ __global__ __launch_bounds__(DUAL_D) void dual_branch_kernel(const DualArgs a) {
         for (int t = 0; t < T; ++t) mx = fmaxf(mx, sc[t]);
         float zs = 0.f, acc = 0.f;
         for (int t = 0; t < T; ++t) { const float e = expf(sc[t] - mx); zs += e; acc = fmaf(e, h[t * D + tid], acc); }
-        a.z[(long long)clip * a.z_ld + tid] = acc / zs;
+        a.z[(long long)clip * a.z_ld + br * D + tid] = acc / zs;
     }
 }
 
@@ -278,32 +282,38 @@ extern "C" int af_transpose_f32(const float* src, int rows, int cols, float* dst
     return AF_OK;
 }
 
-extern "C" int af_dual_branch_encoder(const float* x, const int* lengths, const float* weights, const float* pe, int clips,
-                                      int frames, int din, int d_model, int depth, int heads, int ff, float pool_tau, float* z,
-                                      int z_ld, void* stream) {
+extern "C" int af_dual_branch_encoders(int branches, const float* const* x, const float* const* weights, const int* din,
+                                       const int* lengths, const float* pe, int clips, int frames, int d_model, int depth,
+                                       int heads, int ff, float pool_tau, float* z, int z_ld, void* stream) {
     using namespace af;
-    AF_REQUIRE(x && weights && pe && z && clips >= 0, "dual_branch_encoder: null argument");
-    AF_REQUIRE(d_model == DUAL_D, "dual_branch_encoder: built for d_model = %d (got %d)", DUAL_D, d_model);
-    AF_REQUIRE(frames >= 1 && frames <= DUAL_MAXT, "dual_branch_encoder: 1..%d frames per clip (got %d)", DUAL_MAXT, frames);
-    AF_REQUIRE(din >= 4 && din <= DUAL_D && din % 4 == 0, "dual_branch_encoder: 4..%d input features, a multiple of 4 (got %d)", DUAL_D, din);
-    AF_REQUIRE(depth >= 0 && heads >= 1 && d_model % heads == 0 && heads * frames * frames <= 4 * DUAL_MAXT * DUAL_MAXT,
-               "dual_branch_encoder: bad depth / heads");
-    AF_REQUIRE(ff >= 4 && ff <= DUAL_MAXW && ff % 4 == 0, "dual_branch_encoder: dim_feedforward 4..%d, a multiple of 4 (got %d)", DUAL_MAXW, ff);
-    AF_REQUIRE(z_ld >= d_model, "dual_branch_encoder: z_ld < d_model");
-    if (clips == 0) return AF_OK;
+    AF_REQUIRE(x && weights && din && pe && z && clips >= 0, "dual_branch_encoders: null argument");
+    AF_REQUIRE(branches >= 1 && branches <= DUAL_MAXB, "dual_branch_encoders: 1..%d branches (got %d)", DUAL_MAXB, branches);
+    AF_REQUIRE(d_model == DUAL_D, "dual_branch_encoders: built for d_model = %d (got %d)", DUAL_D, d_model);
+    AF_REQUIRE(frames >= 1 && frames <= DUAL_MAXT, "dual_branch_encoders: 1..%d frames per clip (got %d)", DUAL_MAXT, frames);
+    AF_REQUIRE(depth >= 0 && heads >= 1 && d_model % heads == 0, "dual_branch_encoders: bad depth / heads");
+    AF_REQUIRE(ff >= 4 && ff <= DUAL_MAXW && ff % 4 == 0, "dual_branch_encoders: dim_feedforward 4..%d, a multiple of 4 (got %d)", DUAL_MAXW, ff);
+    AF_REQUIRE(z_ld >= branches * d_model, "dual_branch_encoders: z_ld < branches * d_model");
     DualArgs a;
-    a.x = x; a.lengths = lengths; a.w = weights; a.pe = pe; a.z = z;
-    a.T = frames; a.din = din; a.depth = depth; a.heads = heads; a.ff = ff; a.z_ld = z_ld;
+    for (int b = 0; b < branches; ++b) {
+        AF_REQUIRE(x[b] && weights[b], "dual_branch_encoders: null branch %d", b);
+        AF_REQUIRE(din[b] >= 4 && din[b] <= DUAL_D && din[b] % 4 == 0,
+                   "dual_branch_encoders: 4..%d input features, a multiple of 4 (branch %d has %d)", DUAL_D, b, din[b]);
+        a.x[b] = x[b]; a.w[b] = weights[b]; a.din[b] = din[b];
+    }
+    if (clips == 0) return AF_OK;
+    a.lengths = lengths; a.pe = pe; a.z = z;
+    a.T = frames; a.depth = depth; a.heads = heads; a.ff = ff; a.z_ld = z_ld;
     a.inv_tau = 1.0f / (pool_tau > 1e-3f ? pool_tau : 1e-3f);
     const int tt = frames <= 8 ? 8 : 16;
     const int hmax = heads > 4 ? heads : 4;
     const int lds = (3 * tt * DUAL_D + tt * DUAL_MAXW + hmax * tt * tt) * 4;
+    AF_REQUIRE(lds <= 160 * 1024, "dual_branch_encoders: %d heads do not fit LDS", heads);
     hipStream_t s = (hipStream_t)stream;
     hipError_t e = tt == 8 ? hipFuncSetAttribute(reinterpret_cast<const void*>(&dual_branch_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)
                            : hipFuncSetAttribute(reinterpret_cast<const void*>(&dual_branch_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return set_error(AF_ERR_LAUNCH, "dual_branch_encoder: hipFuncSetAttribute: %s", hipGetErrorString(e));
-    if (tt == 8) hipLaunchKernelGGL((dual_branch_kernel<8>), dim3(clips), dim3(DUAL_D), lds, s, a);
-    else hipLaunchKernelGGL((dual_branch_kernel<16>), dim3(clips), dim3(DUAL_D), lds, s, a);
+    if (e != hipSuccess) return set_error(AF_ERR_LAUNCH, "dual_branch_encoders: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    if (tt == 8) hipLaunchKernelGGL((dual_branch_kernel<8>), dim3(clips, branches), dim3(DUAL_D), lds, s, a);
+    else hipLaunchKernelGGL((dual_branch_kernel<16>), dim3(clips, branches), dim3(DUAL_D), lds, s, a);
     AF_CHECK_LAUNCH("dual_branch_kernel");
     return AF_OK;
 }

@@ -6,7 +6,7 @@ landmark coordinates per clip).
 Each modality runs through a ``BranchEncoder`` (:53-107): Linear + LayerNorm, a first-difference / moving-average
 high-pass mix, a dilated depthwise Conv1d pyramid + pointwise Conv1d + GELU, sinusoidal positions, ``depth`` pre-norm
 ``nn.TransformerEncoderLayer``s (GELU) and a soft attention pooling; the two clip vectors are concatenated and scored by
-LayerNorm -> Linear -> GELU -> Linear.  The whole branch is ONE HIP kernel launch per modality (one workgroup per clip,
+LayerNorm -> Linear -> GELU -> Linear.  Both branches are ONE HIP kernel launch (one workgroup per (clip, modality),
 activations never leave LDS, weights streamed from L2 in a pre-transposed flat buffer), the head a second tiny kernel:
 csrc/af_dual.hip.  The module below only owns the parameters (same ``state_dict`` keys as the reference, 136 of them,
 including the auxiliary heads that inference never evaluates) and the launch plumbing - no CPU / eager fallback.
@@ -251,13 +251,15 @@ class DualEncoderAU_LMK(nn.Module):
             st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
             z = torch.empty((B, 2 * sp.d_model), dtype=torch.float32, device=dev)
             logits = torch.empty((B,), dtype=torch.float32, device=dev)
-            for bi, ((name, din), x) in enumerate(zip(sp.branches(), (A, L))):
-                x = x.to(torch.float32).contiguous()
-                check(lib.af_dual_branch_encoder(C.c_void_p(x.data_ptr()), None if lengths is None else C.c_void_p(lengths.data_ptr()),
-                                                 C.c_void_p(branches[name].data_ptr()), C.c_void_p(self._pe[T].data_ptr()),
-                                                 B, T, din, sp.d_model, sp.depth, sp.heads, sp.ff, C.c_float(sp.pool_tau),
-                                                 C.c_void_p(z.data_ptr() + 4 * bi * sp.d_model), 2 * sp.d_model, st),
-                      "af_dual_branch_encoder")
+            xs = [x.to(torch.float32).contiguous() for x in (A, L)]
+            nb = len(xs)
+            xp = (C.c_void_p * nb)(*[x.data_ptr() for x in xs])
+            wp = (C.c_void_p * nb)(*[branches[name].data_ptr() for name, _ in sp.branches()])
+            dins = (C.c_int * nb)(*[din for _, din in sp.branches()])
+            check(lib.af_dual_branch_encoders(nb, xp, wp, dins, None if lengths is None else C.c_void_p(lengths.data_ptr()),
+                                              C.c_void_p(self._pe[T].data_ptr()), B, T, sp.d_model, sp.depth, sp.heads, sp.ff,
+                                              C.c_float(sp.pool_tau), C.c_void_p(z.data_ptr()), 2 * sp.d_model, st),
+                  "af_dual_branch_encoders")
             check(lib.af_dual_head(C.c_void_p(z.data_ptr()), C.c_void_p(head.data_ptr()), B, 2 * sp.d_model,
                                    C.c_void_p(logits.data_ptr()), st), "af_dual_head")
         out = {"bin_logits": logits, "dom_logits": None}

@@ -65,6 +65,28 @@ def test_ftcn_tt_plugin_layout_and_load(tmp_path):
         c(torch.zeros(1, 3, 32, 224, 224))               # CPU tensor: no fallback
 
 
+def test_dualrun_encoder_layout_and_errors():
+    """dualrun drop-in: 136-key state_dict in the reference's order (asserted against the reference class in
+    oracle/gen_golden.py --dualrun, pinned here by the fixture's counts and the recipe hash); no CPU fallback."""
+    from af_mi355x import dualrun
+    g = load_json("f7_dualrun.json")
+    sp = dualrun.DualSpec()
+    net = dualrun.DualEncoderAU_LMK(mlp_ratio=3.0).eval()
+    sd = net.state_dict()
+    lay = dualrun.dual_state_dict_layout(sp)
+    assert [k for k, _ in lay] == list(sd.keys()) and len(sd) == g["num_keys"]
+    assert all(tuple(sd[k].shape) == tuple(sh) for k, sh in lay)
+    assert sum(p.numel() for p in net.parameters()) == g["num_params"]
+    w = dualrun.dual_synthetic_state_dict(sp, seed=g["weights_seed"])
+    assert synth.state_dict_sha256(w) == g["weights_sha256"]
+    net.load_state_dict(w)
+    A, L, lengths = dualrun.synthetic_dual_inputs(2, sp)
+    with pytest.raises(RuntimeError):
+        net(A, L, lengths)
+    with pytest.raises(NotImplementedError):
+        dualrun.DualEncoderAU_LMK(use_dat=True, domain_classes=3)
+
+
 def test_last_linear_is_head_projection(clf):
     lin = [m for m in clf.modules() if isinstance(m, torch.nn.Linear)][-1]
     assert lin is clf.network.resnet.head.projection and lin.in_features == 2048 and lin.out_features == 1
