@@ -214,6 +214,13 @@ int af_dual_branch_encoders(int branches, const float* const* x, const float* co
  * weights: gamma, beta, W1^T [n][n], b1, w2 [n], b2. */
 int af_dual_head(const float* z, const float* weights, int clips, int n, float* logits, void* stream);
 
+/* GatedMoE.forward (dualrun/rgb/engine_rgb.py:369-384): fuses the RGB (AltFreezing) logit and the dual-encoder logit of n
+ * clips: gate = sigmoid(W2 relu(W1 [z_rgb, z_dual, |z_rgb - z_dual|] + b1) + b2), p = gate * sigmoid(z_rgb / max(t_rgb, 1))
+ * + (1 - gate) * sigmoid(z_dual / max(t_dual, 0.1)), z = logit(p) with eps 1e-6.  weights: t_rgb, t_dual, W1 [hidden][3],
+ * b1, w2 [hidden], b2. */
+int af_gated_moe(const float* z_rgb, const float* z_dual, const float* weights, int hidden, int n, float* z, float* gate,
+                 void* stream);
+
 /* ---- whole-forward op list ------------------------------------------------------------ */
 
 enum af_op_kind { AF_OP_STEM = 0, AF_OP_CONV = 1, AF_OP_MAXPOOL = 2, AF_OP_HEAD = 3,

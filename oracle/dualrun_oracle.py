@@ -77,3 +77,11 @@ def dual_forward(sd, A, L, lengths=None, heads=4, tau=1.0, dtype=torch.float32):
         y = F.gelu(F.linear(y, w("head.1.weight"), w("head.1.bias")))
         logits = F.linear(y, w("head.4.weight"), w("head.4.bias")).squeeze(-1)
     return logits, z
+
+
+def gated_moe(sd, z_rgb, z_dual):
+    """GatedMoE.forward (dualrun/rgb/engine_rgb.py:376-384) -> (fused logit, gate)."""
+    x = torch.cat([z_rgb, z_dual, torch.abs(z_rgb - z_dual)], dim=1)
+    g = torch.sigmoid(F.linear(F.relu(F.linear(x, sd["gate.0.weight"], sd["gate.0.bias"])), sd["gate.2.weight"], sd["gate.2.bias"]))
+    p = g * torch.sigmoid(z_rgb / sd["t_rgb"].clamp_min(1.0)) + (1 - g) * torch.sigmoid(z_dual / sd["t_dual"].clamp_min(0.1))
+    return torch.log((p + 1e-6) / (1 - p + 1e-6)), g

@@ -18,6 +18,7 @@ Fixtures
   f4_load.json      behaviour table of ``ModelBase.load`` on crafted checkpoints
 """
 import json
+from collections import OrderedDict
 import os
 import sys
 import tempfile
@@ -434,6 +435,22 @@ def gen_dualrun():
         out[tag + "_logits_f64"] = o64["bin_logits"].numpy()
         out[tag + "_z_f32"] = o32["z"].numpy()
         print("F7 dualrun", tag, "logits", o32["bin_logits"].numpy().round(5).tolist())
+    # GatedMoE (dualrun/rgb/engine_rgb.py:369-384): fuses the RGB logit with the dual logit; seeded parameters and logits
+    sys.path.insert(0, os.path.join(ref_import.REFERENCE_ROOT, "dualrun"))
+    spec_e = importlib.util.spec_from_file_location("ref_engine_rgb", os.path.join(ref_import.REFERENCE_ROOT, "dualrun", "rgb", "engine_rgb.py"))
+    eng = importlib.util.module_from_spec(spec_e)
+    spec_e.loader.exec_module(eng)
+    moe = eng.GatedMoE().eval()
+    gm = torch.Generator().manual_seed(4711)
+    msd = OrderedDict((k, (torch.randn(v.shape, generator=gm) * 0.8 + (1.5 if k.startswith("t_") else 0.0)))
+                      for k, v in moe.state_dict().items())
+    moe.load_state_dict(msd)
+    zr, zd = torch.randn(9, 1, generator=gm) * 3, torch.randn(9, 1, generator=gm) * 3
+    with torch.no_grad():
+        zf, gate = moe(zr, zd)
+    for k, v in msd.items():
+        out["moe_w_" + k] = v.numpy()
+    out["moe_z_rgb"], out["moe_z_dual"], out["moe_z"], out["moe_gate"] = zr.numpy(), zd.numpy(), zf.numpy(), gate.numpy()
     with open(os.path.join(GOLD, "f7_dualrun.json"), "w") as f:
         json.dump({"source": "reference dualrun/model/dual_encoder.py DualEncoderAU_LMK (au 36, lmk 132, d_model 256, depth 4, "
                              "heads 4, mlp_ratio 3.0, pool_tau 1.0), eval, PyTorch CPU, weights dual_synthetic_state_dict(seed), "

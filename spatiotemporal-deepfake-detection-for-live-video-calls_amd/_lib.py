@@ -79,6 +79,7 @@ ABI = {
     "af_transpose_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "af_dual_branch_encoders": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_void_p,
                                            C.c_void_p] + [C.c_int] * 6 + [C.c_float, C.c_void_p, C.c_int, C.c_void_p]),
+    "af_gated_moe": (C.c_int, [C.c_void_p] * 3 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "af_dual_head": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "af_run_ops": (C.c_int, [C.POINTER(Op), C.c_int, C.c_void_p]),
     "af_run_ops_timed": (C.c_int, [C.POINTER(Op), C.c_int, C.c_void_p, C.POINTER(C.c_float)]),

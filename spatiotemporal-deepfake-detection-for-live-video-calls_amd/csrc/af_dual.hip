@@ -258,6 +258,27 @@ __global__ __launch_bounds__(256) void dual_head_kernel(const float* z, const fl
     if (tid == 0) logits[clip] = red[0] + w2[n];
 }
 
+// GatedMoE.forward (dualrun/rgb/engine_rgb.py:369-384): a 3 -> hidden -> 1 gate on (z_rgb, z_dual, |z_rgb - z_dual|) mixes the
+// two temperature-scaled probabilities; returns the fused logit and the gate.  One thread per clip.
+// w: t_rgb, t_dual, W1 [hidden][3], b1 [hidden], w2 [hidden], b2
+__global__ void gated_moe_kernel(const float* z_rgb, const float* z_dual, const float* w, int hidden, int n, float* z, float* g) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float a = z_rgb[i], b = z_dual[i], d = fabsf(a - b);
+    const float* W1 = w + 2; const float* b1 = W1 + 3 * hidden; const float* w2 = b1 + hidden;
+    float s = w2[hidden];
+    for (int j = 0; j < hidden; ++j) {
+        const float hj = fmaf(W1[3 * j + 2], d, fmaf(W1[3 * j + 1], b, fmaf(W1[3 * j], a, b1[j])));
+        s = fmaf(w2[j], fmaxf(hj, 0.f), s);
+    }
+    const float gate = 1.f / (1.f + expf(-s));
+    const float pr = 1.f / (1.f + expf(-a / fmaxf(w[0], 1.0f)));
+    const float pd = 1.f / (1.f + expf(-b / fmaxf(w[1], 0.1f)));
+    const float p = gate * pr + (1.f - gate) * pd;
+    z[i] = logf((p + 1e-6f) / (1.f - p + 1e-6f));
+    g[i] = gate;
+}
+
 __global__ void transpose_f32_kernel(const float* src, int rows, int cols, float* dst) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long long)rows * cols) return;
@@ -324,5 +345,15 @@ extern "C" int af_dual_head(const float* z, const float* weights, int clips, int
     if (clips == 0) return AF_OK;
     hipLaunchKernelGGL(dual_head_kernel, dim3(clips), dim3(256), (2 * n + 256) * 4, (hipStream_t)stream, z, weights, n, logits);
     AF_CHECK_LAUNCH("dual_head_kernel");
+    return AF_OK;
+}
+
+extern "C" int af_gated_moe(const float* z_rgb, const float* z_dual, const float* weights, int hidden, int n, float* z, float* gate,
+                            void* stream) {
+    using namespace af;
+    AF_REQUIRE(z_rgb && z_dual && weights && z && gate && hidden >= 1 && n >= 0, "gated_moe: bad argument");
+    if (n == 0) return AF_OK;
+    hipLaunchKernelGGL(gated_moe_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, z_rgb, z_dual, weights, hidden, n, z, gate);
+    AF_CHECK_LAUNCH("gated_moe_kernel");
     return AF_OK;
 }

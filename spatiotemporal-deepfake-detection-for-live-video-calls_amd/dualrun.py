@@ -266,3 +266,32 @@ class DualEncoderAU_LMK(nn.Module):
         if return_z:
             out["z"] = z
         return out
+
+
+class GatedMoE(nn.Module):
+    """Drop-in for the reference's ``GatedMoE`` (dualrun/rgb/engine_rgb.py:369-384): fuses the RGB (AltFreezing) logit and
+    the dual-encoder logit of a clip.  ``forward(z_rgb (B,1), z_dual (B,1)) -> (z (B,1), g (B,1))`` on HIP tensors."""
+
+    def __init__(self, hidden: int = 8):
+        super().__init__()
+        self.t_rgb = nn.Parameter(torch.tensor(1.0))
+        self.t_dual = nn.Parameter(torch.tensor(1.0))
+        self.gate = nn.Sequential(nn.Linear(3, hidden), nn.ReLU(), nn.Linear(hidden, 1))
+        self.hidden = hidden
+
+    def forward(self, z_rgb: torch.Tensor, z_dual: torch.Tensor):
+        from ._lib import check, lib
+        if not (z_rgb.is_cuda and z_dual.is_cuda):
+            raise RuntimeError("GatedMoE only runs on HIP device tensors (no CPU fallback)")
+        if z_rgb.shape != z_dual.shape or z_rgb.dim() != 2 or z_rgb.shape[1] != 1:
+            raise ValueError("z_rgb and z_dual must both be (B,1)")
+        dev = z_rgb.device
+        with torch.cuda.device(dev):
+            w = torch.cat([self.t_rgb.reshape(1), self.t_dual.reshape(1), self.gate[0].weight.reshape(-1),
+                           self.gate[0].bias, self.gate[2].weight.reshape(-1), self.gate[2].bias]).detach().float().contiguous()
+            a, b = z_rgb.detach().float().contiguous(), z_dual.detach().float().contiguous()
+            z, g = torch.empty_like(a), torch.empty_like(a)
+            check(lib.af_gated_moe(C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()), C.c_void_p(w.data_ptr()), self.hidden,
+                                   a.numel(), C.c_void_p(z.data_ptr()), C.c_void_p(g.data_ptr()),
+                                   C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "af_gated_moe")
+        return z, g

@@ -67,3 +67,17 @@ def test_dual_encoder_contract_errors(dual):
     with torch.inference_mode():
         e = net(A[:0].cuda(), L[:0].cuda())
     assert e["bin_logits"].shape == (0,)
+
+
+def test_gated_moe_matches_reference():
+    """GatedMoE (dualrun/rgb/engine_rgb.py:369-384) against the reference class's outputs for seeded parameters."""
+    st = load_npz("f7_dualrun.npz")
+    moe = dualrun.GatedMoE()
+    moe.load_state_dict({k[len("moe_w_"):]: torch.from_numpy(st[k]) for k in st.files if k.startswith("moe_w_")})
+    moe = moe.cuda().eval()
+    with torch.inference_mode():
+        z, g = moe(torch.from_numpy(st["moe_z_rgb"]).cuda(), torch.from_numpy(st["moe_z_dual"]).cuda())
+    np.testing.assert_allclose(z.cpu().numpy(), st["moe_z"], rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(g.cpu().numpy(), st["moe_gate"], rtol=1e-5, atol=1e-6)
+    with pytest.raises(RuntimeError):
+        moe(torch.zeros(2, 1), torch.zeros(2, 1))

@@ -154,6 +154,10 @@ def test_dualrun_oracle_matches_reference():
         logits, z = dualrun_oracle.dual_forward(sd, A, L, lengths, heads=sp.heads, tau=sp.pool_tau)
         np.testing.assert_allclose(logits.numpy(), st[tag + "_logits_f32"], rtol=0, atol=2e-6)
         np.testing.assert_allclose(z.numpy(), st[tag + "_z_f32"], rtol=2e-6, atol=5e-6)
+    msd = {k[len("moe_w_"):]: torch.from_numpy(st[k]) for k in st.files if k.startswith("moe_w_")}
+    zf, gate = dualrun_oracle.gated_moe(msd, torch.from_numpy(st["moe_z_rgb"]), torch.from_numpy(st["moe_z_dual"]))
+    np.testing.assert_allclose(zf.numpy(), st["moe_z"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(gate.numpy(), st["moe_gate"], rtol=1e-6, atol=1e-7)
 
 
 def test_checkpoint_unwrap_rules():
