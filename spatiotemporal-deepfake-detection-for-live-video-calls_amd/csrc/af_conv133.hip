@@ -4,15 +4,19 @@
 // The generic implicit GEMM streams every activation row through LDS once PER TAP (9x) and re-reads the
 // weight tile from LDS for every 32 positions; at Cin = Cout = 64 that makes the layer ingest / LDS bound
 // (~0.37 PFLOP/s).  This kernel is shaped around what is small here:
-//   * the whole weight tensor (64 x 9 x 64) lives in REGISTERS: a wave owns 32 output channels and keeps its
-//     36 MFMA A-fragments (9 taps x 2 k-halves x 2 channel tiles = 144 VGPRs) for the life of the workgroup;
-//     the A operand never touches LDS;
+//   * the whole weight tensor (64 x 9 x 64) lives in REGISTERS: 4 waves, ONE per SIMD, each with all 64 output
+//     channels: 72 MFMA A-fragments (9 taps x 2 k-halves x 4 channel tiles = 288 registers, VGPRs + AGPRs - a wave
+//     alone on its SIMD has all 512) for the life of the workgroup; the A operand never touches LDS, a B fragment
+//     feeds 4 MFMAs, and the fragments of the next (tap, k-half) step are read while this one multiplies (with two
+//     waves per SIMD and 32 channels each, the loop was a chain of LDS latencies: read, wait, 2 MFMAs);
 //   * a workgroup walks a contiguous run of image strips (R = 4 output rows); each strip's input patch
 //     ((R+2) rows, zero halo columns included) is brought in ONCE by LDS-DMA (buffer loads; out-of-range lanes = zeros), double-buffered under the MFMAs
 //     of the previous strip, and all 9 taps read it: with the rows stored at a padded pitch WP = W + 2 a tap
 //     (dh,dw) is the constant row offset dh*WP + dw, so every B fragment is a plain swizzled ds_read_b128;
 //   * positions are the padded strip (R x WP, two halo columns per row computed and discarded: 3.4 % waste).
-// Persistent: one workgroup per CU, one barrier per strip (~2 300 MFMA cycles per wave between barriers).
+// Persistent: one workgroup per CU, two barriers per strip (~4 600 MFMA cycles per wave between them).  Results leave
+// through an LDS output tile ([position][64 channels], swizzled like the patches): the workgroup stores whole 128-byte
+// rows, and does so under the MFMAs of the NEXT strip.
 #include "af_common.h"
 
 namespace af {
@@ -31,38 +35,40 @@ struct C133Args {
 
 
 template <int DT, int R>
-__global__ __launch_bounds__(512, 2) void conv133_c64_kernel(const C133Args a) {
+__global__ __launch_bounds__(256, 1) void conv133_c64_kernel(const C133Args a) {
     typedef Elem<DT> E;
     static_assert(E::EPC == 8, "16-bit operands only");
     constexpr int MT = 4;                              // m-tiles per wave (up to 16 per strip)
-    constexpr int PROW = 36;                           // epilogue patch row stride (floats): 32 channels + pad
+    constexpr int OTROWS = 16 * 16;                    // rows of the output tile (16 m-tiles of 16 positions)
 
     extern __shared__ uint4 smem[];
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nh = wave & 1, mg = wave >> 1;           // channel half, m-tile group
+    const int mg = wave;                               // m-tile group: tiles mg, mg + 4, ... (all 64 channels per wave)
+    constexpr int NT4 = 4;                             // channel tiles per wave
     const int frow = lane & 15, fg = lane >> 4;
     const int WP = a.W + 2;
-    const int NT = (R * WP + 15) >> 4;                 // m-tiles per strip (<= 16, host-checked)
     const int NP = a.rows_alloc >> 3;                  // DMA pieces per patch
     const int buf_bytes = a.rows_alloc * 128;
-    float* patch = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + 2 * buf_bytes) + wave * (16 * PROW);
+    // output tile of a strip: [position][64 channels] in the output type, 128-byte rows with the same XOR swizzle as the
+    // patches; every wave drops its 32 channels x 64 positions in, then the whole workgroup streams full rows out
+    char* otile = reinterpret_cast<char*>(smem) + 2 * buf_bytes;
 
     // ---- weights -> registers (A operand: lane = (channel row, k-group))
-    uint4 wreg[9][2][2];
+    uint4 wreg[9][2][NT4];
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int ch = nh * 32 + i * 16 + frow;
+            for (int i = 0; i < NT4; ++i) {
+                const int ch = i * 16 + frow;
                 wreg[tap][kk][i] = *reinterpret_cast<const uint4*>(a.w + ((ch * 9 + tap) * 64 + kk * 32 + fg * 8) * 2);
             }
     // BN scale / shift wait in LDS (the weights take 144 VGPRs; a spill would put scratch loads - and their
     // vmcnt(0), which also waits for the patch DMA in flight - into the strip loop)
-    float* bn_lds = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + 2 * buf_bytes) + 8 * 16 * PROW;
+    float* bn_lds = reinterpret_cast<float*>(otile + OTROWS * 128);
     if (tid < 64) { bn_lds[tid] = a.scale[tid]; bn_lds[64 + tid] = a.shift[tid]; }
 
     // ---- patch producer.  LDS row j of a patch <-> padded pixel q = j - 1 : (r, c') = (q / WP, q % WP), input pixel
@@ -72,7 +78,7 @@ __global__ __launch_bounds__(512, 2) void conv133_c64_kernel(const C133Args a) {
     // Out-of-image lanes get an offset outside the buffer descriptor's range and the hardware writes zeros.
     unsigned* dma_tab = reinterpret_cast<unsigned*>(bn_lds + 128);
     const int dma_row = lane >> 3, dma_chunk = (lane & 7) ^ dma_row;      // LDS row inside a piece; source chunk
-    for (int g = wave; g < NP; g += 8) {
+    for (int g = wave; g < NP; g += 4) {
         const int q = g * 8 + dma_row - 1;
         const int r = q / WP, c = q - r * WP;
         const bool ok = q >= 0 && r < R + 2 && c >= 1 && c <= a.W;
@@ -84,17 +90,42 @@ __global__ __launch_bounds__(512, 2) void conv133_c64_kernel(const C133Args a) {
         const int h0 = (strip - frame * a.strips_per_frame) * R;
         // origin = pixel (h0 - 1, 0) of the frame (one row above the image for the first strip: those lanes are masked)
         const i32x4 desc = make_desc(a.in + ((long long)frame * a.H + h0 - 1) * a.W * 128);
-        for (int g = wave; g < NP; g += 8) {
+        for (int g = wave; g < NP; g += 4) {
             const unsigned e = dma_tab[g * 64 + lane];
             const bool ok = e != 0xffffffffu && (unsigned)(h0 - 1 + (int)(e >> 24)) < (unsigned)a.H;
             blds16(ok ? (e & 0xffffffu) : kOutOfRange, desc, 0, __builtin_amdgcn_readfirstlane(lds0 + buf * buf_bytes + g * 1024));
         }
     };
 
+    // output side: thread -> (row = position in the padded strip, 16-byte chunk) for each of its 4 row stores
+    int out_off[OTROWS * 8 / 256], out_row[OTROWS * 8 / 256];
+#pragma unroll
+    for (int j = 0; j < OTROWS * 8 / 256; ++j) {
+        const int p = (tid + 256 * j) >> 3, r = p / WP, c = p - r * WP;
+        const bool ok = r < R && c >= 1 && c <= a.W;                // halo columns / rows beyond the strip are not stored
+        out_row[j] = r;
+        out_off[j] = ok ? (r * a.W + (c - 1)) * 128 + (tid & 7) * 16 : -1;
+    }
+
     // contiguous run of strips for this workgroup
     const int G = gridDim.x, b = blockIdx.x;
     const int s0 = (int)((long long)a.total_strips * b / G), s1 = (int)((long long)a.total_strips * (b + 1) / G);
     if (s0 < s1) issue_patch(s0, 0);
+
+    // the workgroup streams the output tile of strip `sp` out as whole 128-byte rows, 16 bytes per lane
+    auto store_tile = [&](int sp) {
+        const int frame = sp / a.strips_per_frame;
+        const int h0 = (sp - frame * a.strips_per_frame) * R;
+        char* obase = a.out + ((long long)frame * a.H + h0) * a.W * 128;
+#pragma unroll
+        for (int j = 0; j < OTROWS * 8 / 256; ++j) {
+            if (out_off[j] >= 0 && h0 + out_row[j] < a.H) {
+                const int row = (tid + 256 * j) >> 3, chunk = tid & 7;
+                const u32x4 o = *reinterpret_cast<const u32x4*>(otile + row * 128 + ((chunk ^ (row & 7)) << 4));
+                __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(obase + out_off[j]));
+            }
+        }
+    };
 
     for (int s = s0; s < s1; ++s) {
         const int buf = (s - s0) & 1;
@@ -103,68 +134,64 @@ __global__ __launch_bounds__(512, 2) void conv133_c64_kernel(const C133Args a) {
         if (s + 1 < s1) issue_patch(s + 1, buf ^ 1);
 
         const char* xb = reinterpret_cast<const char*>(smem) + buf * buf_bytes;
-        f32x4 acc[2][MT];
+        f32x4 acc[NT4][MT];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < NT4; ++i)
 #pragma unroll
             for (int k = 0; k < MT; ++k) acc[i][k] = f32x4{0.f, 0.f, 0.f, 0.f};
-        // (a software-pipelined version of this loop - fragment reads one step ahead, no branches - measured slower:
-        // with the weights in 144 VGPRs it spills, and the two waves of a SIMD already cover each other's LDS reads)
+        // 18 (tap, k-half) steps of 16 MFMAs (4 channel tiles x 4 m-tiles); the 4 B fragments of step i+1 are read while
+        // step i multiplies.  One wave per SIMD: nothing else hides the LDS latency, but the whole register file is this
+        // wave's (288 weight registers + 64 accumulators + two fragment sets).  All MT m-tiles are multiplied
+        // unconditionally (a tile index beyond NT reads rows of the other buffer / the output tile - still inside this
+        // workgroup's LDS - and is never stored).
+        uint4 bf[2][MT];
+        auto read_step = [&](int step, uint4 (&b)[MT]) {
+            const int tap = step >> 1, kk = step & 1;
+            const int row = frow + (tap / 3) * WP + (tap % 3);    // + 16 * m-tile: does not change row & 7
+            const char* base = xb + row * 128 + (((kk * 4 + fg) ^ (row & 7)) << 4);
 #pragma unroll
-        for (int dh = 0; dh < 3; ++dh)
+            for (int k = 0; k < MT; ++k) b[k] = *reinterpret_cast<const uint4*>(base + (mg + 4 * k) * (16 * 128));
+        };
+        read_step(0, bf[0]);
 #pragma unroll
-            for (int dw = 0; dw < 3; ++dw) {
-                const int off = dh * WP + dw;                     // tap = constant row offset in the padded patch
+        for (int step = 0; step < 18; ++step) {
+            if (step + 1 < 18) read_step(step + 1, bf[(step + 1) & 1]);
+            if (step == 6 && s > s0) store_tile(s - 1);           // the previous strip's tile leaves under the MFMAs
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk)
+            for (int k = 0; k < MT; ++k)
 #pragma unroll
-                    for (int k = 0; k < MT; ++k) {
-                        const int t = mg + 4 * k;
-                        if (t < NT) {
-                            const int row = t * 16 + frow + off;
-                            const uint4 bf = *reinterpret_cast<const uint4*>(xb + row * 128 + (((kk * 4 + fg) ^ (row & 7)) << 4));
-                            Mma<DT>::run(wreg[dh * 3 + dw][kk][0], bf, acc[0][k]);
-                            Mma<DT>::run(wreg[dh * 3 + dw][kk][1], bf, acc[1][k]);
-                        }
-                    }
-            }
-
-        // ---- epilogue: BN + ReLU, one m-tile at a time through a wave-private fp32 patch -> 16-byte stores
-        const int frame = s / a.strips_per_frame;
-        const int h0 = (s - frame * a.strips_per_frame) * R;
-        const int prow = lane >> 2, pcc = (lane & 3) * 8;
-        f32x4 sc[2], sf[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            sc[i] = *reinterpret_cast<const f32x4*>(bn_lds + nh * 32 + i * 16 + fg * 4);
-            sf[i] = *reinterpret_cast<const f32x4*>(bn_lds + 64 + nh * 32 + i * 16 + fg * 4);
+                for (int i = 0; i < NT4; ++i) Mma<DT>::run(wreg[step >> 1][step & 1][i], bf[step & 1][k], acc[i][k]);
+            __builtin_amdgcn_sched_barrier(0);
         }
+
+        // ---- epilogue: BN + ReLU + rounding in registers -> the strip's output tile in LDS (8 bytes per lane); the tile is
+        // stored to HBM during the NEXT strip's MFMA loop (store_tile above).  Which (row, chunk) a thread stores and
+        // where it lands relative to the strip never changes: worked out once (out_off / out_row).
+        f32x4 sc[NT4], sf[NT4];
+#pragma unroll
+        for (int i = 0; i < NT4; ++i) {
+            sc[i] = *reinterpret_cast<const f32x4*>(bn_lds + i * 16 + fg * 4);
+            sf[i] = *reinterpret_cast<const f32x4*>(bn_lds + 64 + i * 16 + fg * 4);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // every wave has read the previous tile out
+        __builtin_amdgcn_s_barrier();                                       // (raw barrier: the patch DMA stays in flight)
 #pragma unroll
         for (int k = 0; k < MT; ++k) {
-            const int t = mg + 4 * k;
-            if (t < NT) {
+            const int row = (mg + 4 * k) * 16 + frow;                       // position inside the padded strip
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    f32x4 v = acc[i][k] * sc[i] + sf[i];
-                    v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
-                    *reinterpret_cast<f32x4*>(patch + frow * PROW + i * 16 + fg * 4) = v;
-                }
-                __builtin_amdgcn_wave_barrier();
-                const int p = t * 16 + prow;
-                const int r = p / WP, c = p - r * WP;
-                const f32x4 v0 = *reinterpret_cast<const f32x4*>(patch + prow * PROW + pcc);
-                const f32x4 v1 = *reinterpret_cast<const f32x4*>(patch + prow * PROW + pcc + 4);
-                if (r < R && c >= 1 && c <= a.W && h0 + r < a.H) {
-                    uint4 o;
-                    typename E::type* oe = reinterpret_cast<typename E::type*>(&o);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { oe[e] = E::from_f32(v0[e]); oe[4 + e] = E::from_f32(v1[e]); }
-                    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-                    __builtin_nontemporal_store(__builtin_bit_cast(u32x4, o), reinterpret_cast<u32x4*>(a.out + (((long long)frame * a.H + h0 + r) * a.W + (c - 1)) * 128 + (nh * 32 + pcc) * 2));
-                }
-                __builtin_amdgcn_wave_barrier();
+            for (int i = 0; i < NT4; ++i) {
+                f32x4 v = acc[i][k] * sc[i] + sf[i];
+                v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+                const int ch = i * 16 + fg * 4;                             // 4 channels = 8 bytes: half a 16-byte chunk
+                Vec4<DT>::store(otile + row * 128 + (((ch >> 3) ^ (row & 7)) << 4) + (ch & 4) * 2, v);
             }
         }
+    }
+    if (s0 < s1) {                                                          // the last strip's tile
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        store_tile(s1 - 1);
     }
 }
 
@@ -184,7 +211,7 @@ static int launch_c133(C133Args& a, hipStream_t stream) {
     a.strips_per_frame = (a.H + R - 1) / R;
     a.total_strips = a.frames * a.strips_per_frame;
     a.rows_alloc = (((R + 2) * WP + 2 + 16) + 7) & ~7;
-    const int lds = 2 * a.rows_alloc * 128 + 8 * 16 * 36 * 4 + 128 * 4 + (a.rows_alloc / 8) * 64 * 4;
+    const int lds = 2 * a.rows_alloc * 128 + 16 * 16 * 128 + 128 * 4 + (a.rows_alloc / 8) * 64 * 4;
     const int grid = a.total_strips < g_num_cus ? a.total_strips : g_num_cus;
     static bool attr_set = false;
     if (!attr_set) {
@@ -193,7 +220,7 @@ static int launch_c133(C133Args& a, hipStream_t stream) {
         if (e != hipSuccess) return set_error(AF_ERR_LAUNCH, "conv133: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv133_c64_kernel<DT, R>), dim3(grid), dim3(512), lds, stream, a);
+    hipLaunchKernelGGL((conv133_c64_kernel<DT, R>), dim3(grid), dim3(256), lds, stream, a);
     AF_CHECK_LAUNCH("conv133_c64_kernel");
     return AF_OK;
 }
