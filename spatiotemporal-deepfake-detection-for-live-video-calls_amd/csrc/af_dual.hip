@@ -13,7 +13,8 @@
 
 namespace af {
 
-constexpr int DUAL_D = 256;            // d_model the kernels are built for (= threads per workgroup)
+constexpr int DUAL_D = 256;            // d_model the kernels are built for
+constexpr int DUAL_THREADS = 1024;     // 16 waves: the weight stream wants many loads in flight (a branch is latency-bound)
 constexpr int DUAL_MAXT = 16;
 constexpr int DUAL_MAXW = 768;         // widest row kept in LDS (3 * d_model, dim_feedforward)
 
@@ -31,17 +32,24 @@ struct DualArgs {
 
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f)); }
 
-// y[t][n] = act(bias[n] + sum_k x[t][k] * Wt[k][n]) (+ res[t][n]);  x, y, res in LDS, Wt / bias in global memory
+// y[t][n] = act(bias[n] + sum_k x[t][k] * Wt[k][n]) (+ res[t][n]);  x, y, res in LDS, Wt / bias in global memory.
+// The 1024 threads cover the N columns once (N = 768) or G = 1024 / N times (N = 256: the K range is split over G thread
+// groups whose partial sums meet in `part` [G][TT][N], G = 4 for T <= 8, else 2); ends with the workgroup synchronised.
 template <int TT>
 __device__ __forceinline__ void linear_rows(const float* xs, int ldx, int K, const float* Wt, const float* bias, int N,
-                                            float* ys, int ldy, int T, bool gelu, const float* res, int ldr) {
-    for (int n = threadIdx.x; n < N; n += DUAL_D) {
-        float acc[TT];
-        const float b = bias[n];
+                                            float* ys, int ldy, int T, bool gelu, const float* res, int ldr, float* part) {
+    const int tid = threadIdx.x;
+    constexpr int GMAX = TT <= 8 ? 4 : 2;                                // `part` holds GMAX x TT x 256 floats (32 KB)
+    const int G = N * GMAX <= DUAL_THREADS ? GMAX : (N * 2 <= DUAL_THREADS ? 2 : 1);     // N = 256 -> K groups; N = 768 -> 1
+    const int n = tid % N, kg = tid / N;
+    const int kspan = ((K / G + 3) / 4) * 4;                             // K slice per group, a multiple of 4
+    float acc[TT];
 #pragma unroll
-        for (int t = 0; t < TT; ++t) acc[t] = b;
+    for (int t = 0; t < TT; ++t) acc[t] = 0.f;
+    if (kg < G) {
+        const int k0 = kg * kspan, k1 = k0 + kspan < K ? k0 + kspan : K;
 #pragma unroll 4                                                                         // 16 weight loads in flight per thread
-        for (int k = 0; k < K; k += 4) {                                                // K % 4 == 0 (host-checked)
+        for (int k = k0; k < k1; k += 4) {                                              // K % 4 == 0 (host-checked)
             const float w0 = Wt[(long long)k * N + n], w1 = Wt[(long long)(k + 1) * N + n],
                         w2 = Wt[(long long)(k + 2) * N + n], w3 = Wt[(long long)(k + 3) * N + n];
 #pragma unroll
@@ -50,20 +58,38 @@ __device__ __forceinline__ void linear_rows(const float* xs, int ldx, int K, con
                 acc[t] = fmaf(xv.w, w3, fmaf(xv.z, w2, fmaf(xv.y, w1, fmaf(xv.x, w0, acc[t]))));
             }
         }
+    }
+    if (G > 1) {
+        if (kg < G) {
+#pragma unroll
+            for (int t = 0; t < TT; ++t) part[(kg * TT + t) * N + n] = acc[t];
+        }
+        __syncthreads();
+        for (int i = tid; i < T * N; i += DUAL_THREADS) {
+            const int t = i / N, c = i % N;
+            float v = bias[c];
+            for (int g = 0; g < G; ++g) v += part[(g * TT + t) * N + c];
+            if (gelu) v = gelu_erf(v);
+            if (res) v += res[t * ldr + c];
+            ys[t * ldy + c] = v;
+        }
+    } else if (kg < G) {
+        const float b = bias[n];
 #pragma unroll
         for (int t = 0; t < TT; ++t)
             if (t < T) {
-                float v = gelu ? gelu_erf(acc[t]) : acc[t];
+                float v = gelu ? gelu_erf(acc[t] + b) : acc[t] + b;
                 if (res) v += res[t * ldr + n];
                 ys[t * ldy + n] = v;
             }
     }
+    __syncthreads();
 }
 
 // nn.LayerNorm(256) over the rows of an LDS matrix; wave w takes rows w, w + 4, ...
 __device__ __forceinline__ void layernorm_rows(const float* xs, float* ys, int T, const float* gamma, const float* beta) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int t = wave; t < T; t += DUAL_D / 64) {
+    for (int t = wave; t < T; t += DUAL_THREADS / 64) {
         float v[4], s = 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) { v[i] = xs[t * DUAL_D + lane + 64 * i]; s += v[i]; }
@@ -85,36 +111,36 @@ __device__ __forceinline__ void layernorm_rows(const float* xs, float* ys, int T
 }
 
 template <int TT>
-__global__ __launch_bounds__(DUAL_D) void dual_branch_kernel(const DualArgs a) {
+__global__ __launch_bounds__(DUAL_THREADS) void dual_branch_kernel(const DualArgs a) {
     extern __shared__ float sm[];
     constexpr int D = DUAL_D;
     float* h = sm;                          // [TT][D]   the residual stream
     float* y = h + TT * D;                  // [TT][D]   LayerNorm output / scratch
     float* o = y + TT * D;                  // [TT][D]   attention output / input rows
     float* big = o + TT * D;                // [TT][768] qkv, MLP hidden
-    float* sc = big + TT * DUAL_MAXW;       // [heads][TT][TT] attention probabilities; pooling weights
+    float* part = big + TT * DUAL_MAXW;     // [G][TT][D]  partial sums of the K-split linears (32 KB)
+    float* sc = part + 32 * D;          // [heads][TT][TT] attention probabilities; pooling weights
     const int tid = threadIdx.x, clip = blockIdx.x, br = blockIdx.y, T = a.T;
     const int din = a.din[br];
     int len = a.lengths ? a.lengths[clip] : T;
     len = len < 1 ? 1 : (len > T ? T : len);                     // a clip without valid frames keeps frame 0 (:162-166)
 
     // zero the row buffers once: rows >= T feed the (unrolled) row loops with zeros
-    for (int i = tid; i < 3 * TT * D + TT * DUAL_MAXW; i += D) sm[i] = 0.f;
+    for (int i = tid; i < 3 * TT * D + TT * DUAL_MAXW; i += DUAL_THREADS) sm[i] = 0.f;
     __syncthreads();
     const float* xg = a.x[br] + (long long)clip * T * din;
-    for (int i = tid; i < T * din; i += D) o[(i / din) * D + (i % din)] = xg[i];                // din <= 256 (host-checked)
+    for (int i = tid; i < T * din; i += DUAL_THREADS) o[(i / din) * D + (i % din)] = xg[i];                // din <= 256 (host-checked)
     __syncthreads();
 
     const float* w = a.w[br];
     // ---- h = ln_in(proj(x))                                                     (dual_encoder.py:75)
-    linear_rows<TT>(o, D, din, w, w + (long long)din * D, D, y, D, T, false, nullptr, 0);
+    linear_rows<TT>(o, D, din, w, w + (long long)din * D, D, y, D, T, false, nullptr, 0, part);
     w += (long long)din * D + D;
-    __syncthreads();
     layernorm_rows(y, h, T, w, w + D);
     w += 2 * D;
     __syncthreads();
     // ---- first difference + moving-average high-pass mix, depthwise dilated pyramid (thread = channel)   (:77-91)
-    {
+    if (tid < D) {
         const int c = tid;
         float v[TT], m[TT];
 #pragma unroll
@@ -135,20 +161,20 @@ __global__ __launch_bounds__(DUAL_D) void dual_branch_kernel(const DualArgs a) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const int d = 1 << i;
-            const float w0 = w[c * 3 + 0], w1 = w[c * 3 + 1], w2 = w[c * 3 + 2], b = w[3 * D + c];
+            const float* wd = w + i * 4 * D;
+            const float w0 = wd[c * 3 + 0], w1 = wd[c * 3 + 1], w2 = wd[c * 3 + 2], b = wd[3 * D + c];
 #pragma unroll
             for (int t = 0; t < TT; ++t)
                 p[t] += b + (t - d >= 0 ? w0 * m[t - d] : 0.f) + w1 * m[t] + (t + d < TT ? w2 * m[t + d] : 0.f);
-            w += 4 * D;
         }
 #pragma unroll
         for (int t = 0; t < TT; ++t) y[t * D + c] = t < T ? p[t] : 0.f;
     }
+    w += 12 * D;
     __syncthreads();
     // ---- pointwise conv (a Linear over channels) + GELU, + positions                                       (:90-94)
-    linear_rows<TT>(y, D, D, w, w + D * D, D, h, D, T, true, a.pe, D);
+    linear_rows<TT>(y, D, D, w, w + D * D, D, h, D, T, true, a.pe, D, part);
     w += D * D + D;
-    __syncthreads();
 
     const int dh = D / a.heads;
     const float qscale = rsqrtf((float)dh);
@@ -157,10 +183,9 @@ __global__ __launch_bounds__(DUAL_D) void dual_branch_kernel(const DualArgs a) {
         layernorm_rows(h, y, T, w, w + D);
         w += 2 * D;
         __syncthreads();
-        linear_rows<TT>(y, D, D, w, w + 3 * D * D, 3 * D, big, DUAL_MAXW, T, false, nullptr, 0);
+        linear_rows<TT>(y, D, D, w, w + 3 * D * D, 3 * D, big, DUAL_MAXW, T, false, nullptr, 0, part);
         w += 3 * D * D + 3 * D;
-        __syncthreads();
-        for (int i = tid; i < a.heads * T * T; i += D) {
+        for (int i = tid; i < a.heads * T * T; i += DUAL_THREADS) {
             const int s = i % T, t = (i / T) % T, hd = i / (T * T);
             float dot = 0.f;
             const float* q = big + t * DUAL_MAXW + hd * dh;
@@ -169,7 +194,7 @@ __global__ __launch_bounds__(DUAL_D) void dual_branch_kernel(const DualArgs a) {
             sc[(hd * TT + t) * TT + s] = s < len ? dot * qscale : -INFINITY;
         }
         __syncthreads();
-        for (int i = tid; i < a.heads * T; i += D) {
+        for (int i = tid; i < a.heads * T; i += DUAL_THREADS) {
             float* row = sc + (i / T * TT + i % T) * TT;
             float mx = -INFINITY;
             for (int s = 0; s < T; ++s) mx = fmaxf(mx, row[s]);
@@ -179,33 +204,30 @@ __global__ __launch_bounds__(DUAL_D) void dual_branch_kernel(const DualArgs a) {
             for (int s = 0; s < T; ++s) row[s] *= inv;
         }
         __syncthreads();
-        {
-            const int c = tid, hd = c / dh;
-            for (int t = 0; t < T; ++t) {
+        for (int i = tid; i < T * D; i += DUAL_THREADS) {
+            const int c = i % D, t = i / D, hd = c / dh;
+            {
                 float acc = 0.f;
                 for (int s = 0; s < T; ++s) acc = fmaf(sc[(hd * TT + t) * TT + s], big[s * DUAL_MAXW + 2 * D + c], acc);
                 o[t * D + c] = acc;
             }
         }
         __syncthreads();
-        linear_rows<TT>(o, D, D, w, w + D * D, D, h, D, T, false, h, D);          // out_proj + residual (in place: one
-        w += D * D + D;                                                           // thread owns a column of h)
-        __syncthreads();
+        linear_rows<TT>(o, D, D, w, w + D * D, D, h, D, T, false, h, D, part);    // out_proj + residual (in place: an
+        w += D * D + D;                                                           // element of h is read and written by one thread)
         // ---- x = x + linear2(gelu(linear1(norm2(x))))
         layernorm_rows(h, y, T, w, w + D);
         w += 2 * D;
         __syncthreads();
-        linear_rows<TT>(y, D, D, w, w + (long long)D * a.ff, a.ff, big, DUAL_MAXW, T, true, nullptr, 0);
+        linear_rows<TT>(y, D, D, w, w + (long long)D * a.ff, a.ff, big, DUAL_MAXW, T, true, nullptr, 0, part);
         w += (long long)D * a.ff + a.ff;
-        __syncthreads();
-        linear_rows<TT>(big, DUAL_MAXW, a.ff, w, w + (long long)a.ff * D, D, h, D, T, false, h, D);
+        linear_rows<TT>(big, DUAL_MAXW, a.ff, w, w + (long long)a.ff * D, D, h, D, T, false, h, D, part);
         w += (long long)a.ff * D + D;
-        __syncthreads();
     }
     // ---- attention pooling: softmax_t(h v / tau) over the valid frames                                     (:30-47)
     {
         const int lane = tid & 63, wave = tid >> 6;
-        for (int t = wave; t < T; t += D / 64) {
+        for (int t = wave; t < T; t += DUAL_THREADS / 64) {
             float s = 0.f;
 #pragma unroll
             for (int i = 0; i < 4; ++i) s = fmaf(h[t * D + lane + 64 * i], w[lane + 64 * i], s);
@@ -215,7 +237,7 @@ __global__ __launch_bounds__(DUAL_D) void dual_branch_kernel(const DualArgs a) {
         }
     }
     __syncthreads();
-    {
+    if (tid < D) {
         float mx = -INFINITY;
         for (int t = 0; t < T; ++t) mx = fmaxf(mx, sc[t]);
         float zs = 0.f, acc = 0.f;
@@ -327,14 +349,14 @@ extern "C" int af_dual_branch_encoders(int branches, const float* const* x, cons
     a.inv_tau = 1.0f / (pool_tau > 1e-3f ? pool_tau : 1e-3f);
     const int tt = frames <= 8 ? 8 : 16;
     const int hmax = heads > 4 ? heads : 4;
-    const int lds = (3 * tt * DUAL_D + tt * DUAL_MAXW + hmax * tt * tt) * 4;
+    const int lds = (3 * tt * DUAL_D + tt * DUAL_MAXW + 32 * DUAL_D + hmax * tt * tt) * 4;
     AF_REQUIRE(lds <= 160 * 1024, "dual_branch_encoders: %d heads do not fit LDS", heads);
     hipStream_t s = (hipStream_t)stream;
     hipError_t e = tt == 8 ? hipFuncSetAttribute(reinterpret_cast<const void*>(&dual_branch_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)
                            : hipFuncSetAttribute(reinterpret_cast<const void*>(&dual_branch_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return set_error(AF_ERR_LAUNCH, "dual_branch_encoders: hipFuncSetAttribute: %s", hipGetErrorString(e));
-    if (tt == 8) hipLaunchKernelGGL((dual_branch_kernel<8>), dim3(clips, branches), dim3(DUAL_D), lds, s, a);
-    else hipLaunchKernelGGL((dual_branch_kernel<16>), dim3(clips, branches), dim3(DUAL_D), lds, s, a);
+    if (tt == 8) hipLaunchKernelGGL((dual_branch_kernel<8>), dim3(clips, branches), dim3(DUAL_THREADS), lds, s, a);
+    else hipLaunchKernelGGL((dual_branch_kernel<16>), dim3(clips, branches), dim3(DUAL_THREADS), lds, s, a);
     AF_CHECK_LAUNCH("dual_branch_kernel");
     return AF_OK;
 }
