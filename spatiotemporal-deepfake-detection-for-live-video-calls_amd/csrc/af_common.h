@@ -40,6 +40,11 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 bool conv133_applies(const af_conv_desc* d, const void* residual, int out_ld);
 int conv133_run(const af_conv_desc* d, const void* in, const void* w_packed, const float* scale, const float* shift,
                 void* out, hipStream_t stream);
+// af_conv_small.hip: direct-gather MFMA path for narrow layers (<= 16 output channels, <= 32 K chunks): SlowFast's Fast pathway
+bool conv_small_applies(const af_conv_desc* d, const af_conv_desc* d2, const void* residual, int out_ld);
+int conv_small_run(const af_conv_desc* d, const void* in, const void* w_packed, const af_conv_desc* d2, const void* in2,
+                   const void* w2_packed, const float* scale, const float* shift, const void* residual, void* out, int out_ld,
+                   hipStream_t stream);
 // af_conv311.hip: time-tiled 3x1x1 -> 64 channels kernel (s2 `a` convs): the three taps share one LDS image
 bool conv311_applies(const af_conv_desc* d, const void* residual, int out_ld);
 int conv311_run(const af_conv_desc* d, const void* in, const void* w_packed, const float* scale, const float* shift,
