@@ -1,7 +1,9 @@
 // Stem with the max-pool fused: Conv3d(3->64,[kt,7,7],s[1,2,2]) + BN + ReLU + MaxPool3d([1,3,3],s[1,2,2],p[0,1,1])
 // (reference altfreezing/slowfast/models/stem_helper.py:156-178) as ONE launch, 16-bit operands.
 //
-// A persistent workgroup owns one output frame (n, t) and streams its conv rows top to bottom, two at a time:
+// A persistent workgroup owns one output frame (n, t) - or, when there are fewer frames than CUs (small batches: the
+// live-call case is ONE clip = 32 frames), one band of its pooled rows - and streams the conv rows top to bottom, two
+// at a time:
 //   * all kt*7 weight slices (64 x 1120, 143 KB in 16-bit) are loaded into LDS once per frame - the un-fused
 //     kernel re-fetches them for every 256 positions;
 //   * wave w owns the 16-column tile w of BOTH rows of the pair (2 m-tiles x 4 channel tiles): the 3-row
@@ -25,6 +27,7 @@ struct StemPoolArgs {
     int To, Ho, Wo;      // conv output dims
     int Hq, Wq;          // pooled dims
     int frames;          // N*To
+    int bands, band_rows;// pooled-row bands per frame (work unit = (frame, band)), pooled rows per band
 };
 
 template <int DT, int KT>
@@ -59,8 +62,13 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const StemPoolArgs a)
     int wo = wave * 16 + frow;
     if (wo > a.Wo - 1) wo = a.Wo - 1;                          // clamp: loads stay inside the row, result discarded
 
-    for (int frame = blockIdx.x; frame < a.frames; frame += gridDim.x) {
+    for (int unit = blockIdx.x; unit < a.frames * a.bands; unit += gridDim.x) {
+        const int frame = unit / a.bands, band = unit - frame * a.bands;
         const int n = frame / a.To, to = frame - n * a.To;
+        // pooled rows [j_begin, j_end) of this frame; a band that does not start at the top first runs the row pair above
+        // it (not stored) to get the conv row its first pooled row reaches up to
+        const int j_begin = band * a.band_rows, j_end = (j_begin + a.band_rows < a.Hq) ? j_begin + a.band_rows : a.Hq;
+        const int j_first = j_begin > 0 ? j_begin - 1 : 0;
         // padded coords of tap (0,0,0) for conv output (to, ho, wo): t = to, h = 2*ho, w = 2*wo
         const char* fin = a.in + ((long long)(n * a.Tp + to) * a.Hp) * row_bytes + (long long)(2 * wo) * PIXB + fg * 16;
         f32x4 prev[TN];                                        // conv row 2j-1 (post-ReLU); 0 == -inf after a ReLU
@@ -69,15 +77,17 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const StemPoolArgs a)
         __syncthreads();                                       // weights visible (first frame) / line free
         uint4 b0[KH], b1[KH];                                  // current dt plane's fragments for conv rows 2j, 2j+1
         if (active) {
-            const char* x1 = fin + (long long)(2 * (a.Ho > 1 ? 1 : 0)) * row_bytes;
+            const int h1f = (2 * j_first + 1 < a.Ho) ? 2 * j_first + 1 : a.Ho - 1;
+            const char* x0 = fin + (long long)(2 * (2 * j_first)) * row_bytes;
+            const char* x1 = fin + (long long)(2 * h1f) * row_bytes;
 #pragma unroll
             for (int dh = 0; dh < KH; ++dh) {
-                b0[dh] = *reinterpret_cast<const uint4*>(fin + dh * row_bytes);
+                b0[dh] = *reinterpret_cast<const uint4*>(x0 + dh * row_bytes);
                 b1[dh] = *reinterpret_cast<const uint4*>(x1 + dh * row_bytes);
             }
         }
 
-        for (int j = 0; j < a.Hq; ++j) {
+        for (int j = j_first; j < j_end; ++j) {
             f32x4 acc[2][TN];
 #pragma unroll
             for (int r = 0; r < 2; ++r)
@@ -90,7 +100,7 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const StemPoolArgs a)
 #pragma unroll
                 for (int dt = 0; dt < KT; ++dt) {
                     uint4 n0[KH], n1[KH];
-                    const bool more = dt + 1 < KT || j + 1 < a.Hq;
+                    const bool more = dt + 1 < KT || j + 1 < j_end;
                     if (more) {
                         const int jn = dt + 1 < KT ? j : j + 1, dtn = dt + 1 < KT ? dt + 1 : 0;
                         const int h0n = 2 * jn, h1n = (2 * jn + 1 < a.Ho) ? 2 * jn + 1 : a.Ho - 1;
@@ -141,7 +151,7 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const StemPoolArgs a)
             }
             __syncthreads();
             // horizontal 3-max, stride 2: pooled col q <- conv cols 2q-1, 2q, 2q+1; 8 channels (16 B) per thread
-            for (int idx = tid; idx < a.Wq * 8; idx += 512) {
+            for (int idx = tid; idx < (j >= j_begin ? a.Wq * 8 : 0); idx += 512) {
                 const int q = idx >> 3, ch = (idx & 7) * 8;
                 float m[8];
 #pragma unroll
@@ -187,7 +197,8 @@ static int launch_stem_pool_kt(const StemPoolArgs& a, hipStream_t stream) {
         if (e != hipSuccess) return set_error(AF_ERR_LAUNCH, "stem_pool: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
     }
-    const int grid = a.frames < g_cus ? a.frames : g_cus;     // one resident workgroup per CU; weights loaded once each
+    const int units = a.frames * a.bands;
+    const int grid = units < g_cus ? units : g_cus;           // one resident workgroup per CU; weights loaded once each
     hipLaunchKernelGGL((stem_pool_kernel<DT, KT>), dim3(grid), dim3(512), lds, stream, a);
     AF_CHECK_LAUNCH("stem_pool_kernel");
     return AF_OK;
@@ -225,6 +236,17 @@ extern "C" int af_stem_conv_bn_relu_maxpool(const af_conv_desc* d, const void* s
     a.kt = d->kt; a.To = to; a.Ho = ho; a.Wo = wo;
     a.Hq = (ho - 1) / 2 + 1; a.Wq = (wo - 1) / 2 + 1;
     a.frames = d->n * to;
+    // fewer frames than CUs (batch < 8 clips of 32 frames): cut every frame into bands of pooled rows so that the whole
+    // chip works; a band costs one extra (unstored) row pair, so no bands once the frames alone fill the CUs
+    {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+        int bands = a.frames >= cus ? 1 : cus / a.frames;
+        if (bands > a.Hq / 4) bands = a.Hq / 4 > 0 ? a.Hq / 4 : 1;      // at least 4 pooled rows per band
+        a.band_rows = (a.Hq + bands - 1) / bands;
+        a.bands = (a.Hq + a.band_rows - 1) / a.band_rows;
+    }
     a.in += (long long)(AF_STEM_PAD_T - d->pt) * a.Hp * a.Wp * 4 * dtype_size(d->dtype);
     hipStream_t s = (hipStream_t)stream;
     return d->dtype == AF_BF16 ? launch_stem_pool<AF_BF16>(a, s) : launch_stem_pool<AF_F16>(a, s);

@@ -110,7 +110,9 @@ def test_stem_unfused_path_and_odd_sizes(golden_f3, dtype):
     lay = [("s.conv.weight", (64, 3, 5, 7, 7), "float32"), ("s.bn.weight", (64,), "float32"), ("s.bn.bias", (64,), "float32"),
            ("s.bn.running_mean", (64,), "float32"), ("s.bn.running_var", (64,), "float32")]
     sd = synth.fill_layout(lay, 91)
-    for shape in ((1, 3, 3, 33, 37), (2, 3, 2, 18, 70)):          # conv out 17x19 and 9x35
+    # conv out 17x19 and 9x35; then a frame count far below the CU count with a tall image: the fused stem cuts every
+    # frame into 4 bands of pooled rows (5, 5, 5, 3 of 18), each started with an unstored row pair for the pool's upper row
+    for shape in ((1, 3, 3, 33, 37), (2, 3, 2, 18, 70), (1, 3, 4, 70, 40)):
         x = synth.synthetic_tensor(shape, 92 + shape[3])
         want = oracle.stem(x, sd, "s")
         _close(hip_stem(x, sd, "s", dtype, fused=True), want, dtype, "stem %s" % (shape,), scale=3.0)
