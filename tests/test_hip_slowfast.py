@@ -84,7 +84,7 @@ def test_slowfast_batch_and_errors(sf_weights):
     with torch.inference_mode():
         yb = net(x)["final_output"]
         y0 = net(x[:1])["final_output"]
-    assert yb.shape == (2, 1) and torch.equal(yb[:1], y0)
+    assert yb.shape == (2, 1) and torch.allclose(yb[:1], y0, rtol=0, atol=2e-3)     # f16; batch sizes may split K differently
     with pytest.raises(ValueError):
         net([x, x, x])
     with pytest.raises(ValueError):
