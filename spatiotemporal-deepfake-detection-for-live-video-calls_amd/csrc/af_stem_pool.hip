@@ -75,15 +75,16 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const StemPoolArgs a)
 #pragma unroll
         for (int i = 0; i < TN; ++i) prev[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         __syncthreads();                                       // weights visible (first frame) / line free
-        uint4 b0[KH], b1[KH];                                  // current dt plane's fragments for conv rows 2j, 2j+1
+        // current dt plane's fragments: conv row 2j reads padded input rows 4j .. 4j+6, conv row 2j+1 rows 4j+2 .. 4j+8 -
+        // NINE distinct rows for the pair, fetched once (row index clamped to the padded image: only a discarded odd
+        // row of an odd-height image ever reaches past it)
+        constexpr int NR = KH + 2;
+        uint4 bx[NR];
         if (active) {
-            const int h1f = (2 * j_first + 1 < a.Ho) ? 2 * j_first + 1 : a.Ho - 1;
-            const char* x0 = fin + (long long)(2 * (2 * j_first)) * row_bytes;
-            const char* x1 = fin + (long long)(2 * h1f) * row_bytes;
 #pragma unroll
-            for (int dh = 0; dh < KH; ++dh) {
-                b0[dh] = *reinterpret_cast<const uint4*>(x0 + dh * row_bytes);
-                b1[dh] = *reinterpret_cast<const uint4*>(x1 + dh * row_bytes);
+            for (int r = 0; r < NR; ++r) {
+                const int row = 4 * j_first + r < a.Hp ? 4 * j_first + r : a.Hp - 1;
+                bx[r] = *reinterpret_cast<const uint4*>(fin + (long long)row * row_bytes);
             }
         }
 
@@ -94,38 +95,35 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const StemPoolArgs a)
 #pragma unroll
                 for (int i = 0; i < TN; ++i) acc[r][i] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (active) {
-                // activation fragments of one dt plane (7 kernel rows x 2 conv rows = 14 aligned 16-byte loads) are
+                // activation fragments of one dt plane (9 input rows feed the 7 kernel rows of both conv rows: 9 aligned 16-byte loads) are
                 // fetched a whole plane ahead of the MFMAs that use them - the last plane of a row pair prefetches
                 // the first plane of the next pair; everything is unrolled, so the "copy" is register renaming
 #pragma unroll
                 for (int dt = 0; dt < KT; ++dt) {
-                    uint4 n0[KH], n1[KH];
+                    uint4 nx[NR];
                     const bool more = dt + 1 < KT || j + 1 < j_end;
                     if (more) {
                         const int jn = dt + 1 < KT ? j : j + 1, dtn = dt + 1 < KT ? dt + 1 : 0;
-                        const int h0n = 2 * jn, h1n = (2 * jn + 1 < a.Ho) ? 2 * jn + 1 : a.Ho - 1;
-                        const char* y0 = fin + (long long)(2 * h0n) * row_bytes + dtn * plane_bytes;
-                        const char* y1 = fin + (long long)(2 * h1n) * row_bytes + dtn * plane_bytes;
 #pragma unroll
-                        for (int dh = 0; dh < KH; ++dh) {
-                            n0[dh] = *reinterpret_cast<const uint4*>(y0 + dh * row_bytes);
-                            n1[dh] = *reinterpret_cast<const uint4*>(y1 + dh * row_bytes);
+                        for (int r = 0; r < NR; ++r) {
+                            const int row = 4 * jn + r < a.Hp ? 4 * jn + r : a.Hp - 1;
+                            nx[r] = *reinterpret_cast<const uint4*>(fin + (long long)row * row_bytes + dtn * plane_bytes);
                         }
                     }
-                    __builtin_amdgcn_sched_barrier(0);         // keep the 14 loads AHEAD of this plane's MFMAs (hipcc sinks them otherwise)
+                    __builtin_amdgcn_sched_barrier(0);         // keep the 9 loads AHEAD of this plane's MFMAs (hipcc sinks them otherwise)
 #pragma unroll
                     for (int dh = 0; dh < KH; ++dh) {
                         const uint4* wrow = wl + ((dt * KH + dh) * NCH + fg) * COUT + frow;
 #pragma unroll
                         for (int i = 0; i < TN; ++i) {
                             const uint4 af = wrow[i * 16];
-                            Mma<DT>::run(af, b0[dh], acc[0][i]);
-                            Mma<DT>::run(af, b1[dh], acc[1][i]);
+                            Mma<DT>::run(af, bx[dh], acc[0][i]);
+                            Mma<DT>::run(af, bx[dh + 2], acc[1][i]);
                         }
                     }
                     if (more) {
 #pragma unroll
-                        for (int dh = 0; dh < KH; ++dh) { b0[dh] = n0[dh]; b1[dh] = n1[dh]; }
+                        for (int r = 0; r < NR; ++r) bx[r] = nx[r];
                     }
                 }
             }
