@@ -50,6 +50,13 @@ bool conv311_applies(const af_conv_desc* d, const void* residual, int out_ld);
 int conv311_run(const af_conv_desc* d, const void* in, const void* w_packed, const float* scale, const float* shift,
                 void* out, int out_ld, hipStream_t stream);
 
+// af_conv111.hip: persistent weights-in-registers 1x1x1 stream (short-K `c` convs of s2 / s3, with the projection
+// shortcut, the residual and the temporal pool), 16-bit dtypes
+bool conv111_applies(const af_conv_desc* d, const af_conv_desc* d2, const void* residual, int out_ld);
+int conv111_run(const af_conv_desc* d, const void* in, const void* w_packed, const af_conv_desc* d2, const void* in2,
+                const void* w2_packed, const float* scale, const float* shift, const void* residual, void* out, int out_ld,
+                hipStream_t stream);
+
 #define AF_REQUIRE(cond, ...)                                    \
     do {                                                         \
         if (!(cond)) return af::set_error(AF_ERR_ARG, __VA_ARGS__); \

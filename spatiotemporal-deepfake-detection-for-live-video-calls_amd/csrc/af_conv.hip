@@ -536,13 +536,14 @@ static int launch(const ConvArgs& a, hipStream_t stream) {
 // output: half-height tiles with a trimmed ring so several workgroups share a CU and overlap each
 // other's load / store phases.
 enum { VAR_128x256 = 0, VAR_64x256 = 1, VAR_128x128 = 2, VAR_64x128 = 3, VAR_C133 = 4, VAR_128x128_R2 = 5, VAR_256x256 = 6,
-       VAR_128x512 = 7, VAR_C311 = 8, VAR_SMALL = 9, VAR_COUNT = 10 };
+       VAR_128x512 = 7, VAR_C311 = 8, VAR_SMALL = 9, VAR_C111 = 10, VAR_COUNT = 11 };
 static const char* const kVariantNames[] = {"conv_igemm<BN=128,BM=256>", "conv_igemm<BN=64,BM=256>",
                                             "conv_igemm<BN=128,BM=128>", "conv_igemm<BN=64,BM=128>",
                                             "conv133_c64<weights in registers>", "conv_igemm<BN=128,BM=128>",
                                             "conv_igemm<BN=256,BM=256>", "conv_igemm<BN=128,BM=512>",
                                             "conv311_c64<time-tiled, taps share one LDS image>",
-                                            "conv_small<direct-gather MFMA, narrow layers>"};
+                                            "conv_small<direct-gather MFMA, narrow layers>",
+                                            "conv111_stream<persistent, weights in registers>"};
 
 static int pick_variant(int cout, int cin, int taps, int dtype, long long M, int cin2 = 0, int pooled = 0) {
     const int ksteps = (taps * cin + cin2) / (dtype == AF_F32 ? 32 : 64);
@@ -673,6 +674,7 @@ extern "C" int af_conv_variant(const af_conv_desc* d, const af_conv_desc* d2) {
     if (af::conv_small_applies(d, d2, nullptr, 0)) return af::VAR_SMALL;
     if (!d2 && af::conv133_applies(d, nullptr, 0)) return af::VAR_C133;
     if (!d2 && af::conv311_applies(d, nullptr, 0)) return af::VAR_C311;
+    if (af::conv111_applies(d, d2, nullptr, 0)) return af::VAR_C111;
     const int bk = d->dtype == AF_F32 ? 32 : 64;
     return af::pick_variant((d->cout + 63) / 64 * 64, (d->cin + bk - 1) / bk * bk, d->kt * d->kh * d->kw, d->dtype,
                             (long long)d->n * d->to * d->ho * d->wo, d2 ? (d2->cin + bk - 1) / bk * bk : 0, d->tpool);
@@ -746,6 +748,8 @@ static int conv_common(const af_conv_desc* d, const void* in, const void* w_pack
     }
     if (small)
         return conv_small_run(d, in, w_packed, d2, in2, w2_packed, scale, shift, residual, out, out_ld, (hipStream_t)stream);
+    if (conv111_applies(d, d2, residual, out_ld))
+        return conv111_run(d, in, w_packed, d2, in2, w2_packed, scale, shift, residual, out, out_ld, (hipStream_t)stream);
     hipStream_t s = (hipStream_t)stream;
     switch (d->dtype) {
         case AF_F32: return dispatch<AF_F32>(a, s);

@@ -100,6 +100,7 @@ def conv_dual(x_ndhwc, w_oidhw, bn, x2_ndhwc, w2_oidhw, bn2, stride2, dtype):
     # keep every device buffer referenced until the launch has been enqueued (the caching allocator would
     # otherwise hand the first packed weight's memory to the second)
     pw, pw2, shift_sum = _pack_scaled(w_oidhw, scale, dtype), _pack_scaled(w2_oidhw, scale2, dtype), (shift + shift2).contiguous()
+    conv_dual.last_variant = L.lib.af_conv_variant(C.byref(d), C.byref(d2))
     L.check(L.lib.af_conv3d_dual_bn_act(C.byref(d), _p(x_ndhwc), _p(pw), C.byref(d2), _p(x2_ndhwc), _p(pw2), _p(ones),
                                         _p(shift_sum), _p(out), 0, _stream()), "conv3d_dual_bn_act")
     torch.cuda.current_stream().synchronize()

@@ -172,10 +172,17 @@ CONV_CASES = [
     ("t311_256to64_T16", 256, 64, (3, 1, 1), (1, 1, 1), (1, 0, 0), (1, 16, 10, 10), True, False),
     ("t311_256to64_T32_many", 256, 64, (3, 1, 1), (1, 1, 1), (1, 0, 0), (3, 32, 28, 28), False, False),
     ("t311_256to128_T16", 256, 128, (3, 1, 1), (1, 1, 1), (1, 0, 0), (2, 16, 9, 9), True, False),   # 128-row tiles; fp32 -> generic
+    # persistent 1x1x1 stream (weights in registers, residual prefetched a tile ahead): needs >= 4 tiles per CU;
+    # full tiles, a ragged last tile, two channel columns (512 outputs), K = 64 and 128
+    ("stream111_64to256_res", 64, 256, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 8, 96, 96), True, True),
+    ("stream111_64to256_ragged", 64, 256, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 9, 121, 121), True, False),
+    ("stream111_128to512_res_ragged", 128, 512, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 6, 107, 109), False, True),
 ]
 EXPECT_VARIANT = {"tile256_1x3x3_res": 6, "tile256_ragged_m": 6, "tile512_1x3x3_res": 7, "tile512_ragged_m": 7,
                   "t311_64to64_T32": 8, "t311_256to64_T16": 8, "t311_256to64_T32_many": 8,
-                  "t311_256to128_T16": {"f32": 3, "f16": 8, "bf16": 8}}
+                  "t311_256to128_T16": {"f32": 3, "f16": 8, "bf16": 8},
+                  "stream111_64to256_res": {"f32": 2, "f16": 10, "bf16": 10}, "stream111_64to256_ragged": {"f32": 2, "f16": 10, "bf16": 10},
+                  "stream111_128to512_res_ragged": {"f32": 5, "f16": 10, "bf16": 10}}
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -211,7 +218,8 @@ def test_conv_vs_oracle(case, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("cin,cout,dims", [(64, 256, (2, 6, 9, 7)), (64, 64, (1, 4, 5, 5))])
+@pytest.mark.parametrize("cin,cout,dims", [(64, 256, (2, 6, 9, 7)), (64, 64, (1, 4, 5, 5)),
+                                           (64, 256, (2, 16, 63, 65))])     # persistent stream: 1024 tiles, ragged 64-pixel chunks
 def test_conv_with_fused_temporal_maxpool(dtype, cin, cout, dims):
     """s2's last 1x1x1 (+ residual + ReLU) with pathway0_pool = MaxPool3d([2,1,1]) fused into its epilogue."""
     seed = 4242 + cout
@@ -227,9 +235,35 @@ def test_conv_with_fused_temporal_maxpool(dtype, cin, cout, dims):
     want = F.max_pool3d(F.relu(y + res.double()), (2, 1, 1), (2, 1, 1))
     got = hh.conv_bn_act(hh.to_ndhwc(x, dtype), sd["w.weight"], *hh.fold_bn(sd, "bn"), (1, 1, 1), (0, 0, 0), True, dtype,
                          residual=hh.to_ndhwc(res, dtype), tpool=True)
+    if dims[2] * dims[3] > 4000 and dtype != "f32":
+        assert hh.conv_bn_act.last_variant == 10, hh.conv_bn_act.last_variant
     got = hh.to_ncdhw(got).double()
     assert got.shape == want.shape
     tol = {"f32": 2e-6, "f16": 1.5e-3, "bf16": 1.2e-2}[dtype]
+    assert (got - want).abs().max().item() <= tol * want.abs().max().item()
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+def test_projection_shortcut_stream_at_size(dtype):
+    """relu(bn(c(x)) + bn1(branch1(x2))) of s2's first block at a size that takes the persistent 1x1x1 stream (two 64-channel
+    K slabs from two inputs, no residual), ragged last tile; against the oracle on pre-rounded operands."""
+    dims, cin, cout, seed = (1, 10, 115, 115), 64, 256, 909          # 132250 positions = 1033 tiles + 26 rows
+    lay = []
+    for nm in ("c", "b1"):
+        lay += [(nm + ".weight", (cout, cin, 1, 1, 1), "float32"), (nm + "_bn.weight", (cout,), "float32"), (nm + "_bn.bias", (cout,), "float32"),
+                (nm + "_bn.running_mean", (cout,), "float32"), (nm + "_bn.running_var", (cout,), "float32")]
+    sd = synth.fill_layout(lay, seed)
+    x = synth.synthetic_tensor((dims[0], cin) + dims[1:], seed).to(hh.TORCH_DT[dtype]).float()
+    x2 = synth.synthetic_tensor((dims[0], cin) + dims[1:], seed + 1).to(hh.TORCH_DT[dtype]).float()
+    sdd = {k: v.double() for k, v in sd.items()}
+    want = F.relu(oracle.conv_bn_act(x.double(), sdd["c.weight"], sdd, "c_bn", (1, 1, 1), (0, 0, 0), False) +
+                  oracle.conv_bn_act(x2.double(), sdd["b1.weight"], sdd, "b1_bn", (1, 1, 1), (0, 0, 0), False))
+    got = hh.conv_dual(hh.to_ndhwc(x, dtype), sd["c.weight"], hh.fold_bn(sd, "c_bn"), hh.to_ndhwc(x2, dtype), sd["b1.weight"],
+                       hh.fold_bn(sd, "b1_bn"), (1, 1, 1), dtype)
+    assert hh.conv_dual.last_variant == 10, hh.conv_dual.last_variant
+    got = hh.to_ncdhw(got).double()
+    # the BN scales are folded into the packed weights here (one more rounding of each weight than the single-input cases)
+    tol = {"f16": 3e-3, "bf16": 2.4e-2}[dtype]
     assert (got - want).abs().max().item() <= tol * want.abs().max().item()
 
 
