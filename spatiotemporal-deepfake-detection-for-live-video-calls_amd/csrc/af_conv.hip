@@ -543,7 +543,7 @@ static const char* const kVariantNames[] = {"conv_igemm<BN=128,BM=256>", "conv_i
                                             "conv_igemm<BN=256,BM=256>", "conv_igemm<BN=128,BM=512>",
                                             "conv311_c64<time-tiled, taps share one LDS image>",
                                             "conv_small<direct-gather MFMA, narrow layers>",
-                                            "conv111_stream<persistent, weights in registers>"};
+                                            "conv111<persistent stream, weights in registers>"};
 
 static int pick_variant(int cout, int cin, int taps, int dtype, long long M, int cin2 = 0, int pooled = 0) {
     const int ksteps = (taps * cin + cin2) / (dtype == AF_F32 ? 32 : 64);
