@@ -34,6 +34,11 @@ __device__ __forceinline__ i32x4 make_desc(const char* base) {
     return d;
 }
 
+// ReLU and pooling max with torch's NaN behaviour: a NaN activation stays NaN through clamp_min / max_pool, so a clip
+// with a non-finite pixel yields a NaN logit (as in the reference) instead of a plausible score
+__device__ __forceinline__ float relu_f(float v) { return v < 0.f ? 0.f : v; }
+__device__ __forceinline__ float max_nan(float m, float x) { return (x > m || x != x) ? x : m; }
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // af_conv133.hip: register-resident-weights 1x3x3 64->64 kernel (s2 `b` convs), 16-bit dtypes

@@ -414,7 +414,7 @@ __global__ __launch_bounds__(WN * WM * KS * 64, MINW) void conv_igemm_kernel(con
                         const f32x4 t = *reinterpret_cast<const f32x4*>(patch + (4 * prow + p4) * PROW + cc + e);
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            const float x = a.relu ? (t[q] != t[q] ? t[q] : fmaxf(t[q], 0.f)) : t[q];
+                            const float x = a.relu ? relu_f(t[q]) : t[q];
                             v[e + q] = (p4 == 0 || x > v[e + q] || x != x) ? x : v[e + q];   // NaN propagates like ATen's max_pool
                         }
                     }
@@ -458,7 +458,7 @@ __global__ __launch_bounds__(WN * WM * KS * 64, MINW) void conv_igemm_kernel(con
 #pragma unroll
                     for (int e = 0; e < EPC; ++e) {
                         float x0 = v[0][e], x1 = v[1][e];
-                        if (a.relu) { x0 = fmaxf(x0, 0.f); x1 = fmaxf(x1, 0.f); }
+                        if (a.relu) { x0 = relu_f(x0); x1 = relu_f(x1); }
                         oe[e] = E::from_f32((x1 > x0 || x1 != x1) ? x1 : x0);      // NaN propagates like ATen's max_pool
                     }
                     __builtin_nontemporal_store(__builtin_bit_cast(u32x4, o), reinterpret_cast<u32x4*>(a.out + ((m >> 1) * a.out_ld + ch0) * ES));
@@ -491,7 +491,7 @@ __global__ __launch_bounds__(WN * WM * KS * 64, MINW) void conv_igemm_kernel(con
                     }
                     if (a.relu) {
 #pragma unroll
-                        for (int e = 0; e < EPC; ++e) v[e] = fmaxf(v[e], 0.f);
+                        for (int e = 0; e < EPC; ++e) v[e] = relu_f(v[e]);
                     }
                     uint4 o;
                     typename E::type* oe = reinterpret_cast<typename E::type*>(&o);
@@ -582,7 +582,7 @@ __global__ void splitk_finish_kernel(const float* ws, int ksplit, long long M, i
     for (int y = 0; y < ksplit; ++y) v += *reinterpret_cast<const f32x4*>(ws + ((long long)y * M + m) * Cout + c);
     v = v * *reinterpret_cast<const f32x4*>(scale + c) + *reinterpret_cast<const f32x4*>(shift + c);
     if (res) v += Vec4<DT>::load(res + (m * Cout + c) * ES);
-    if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+    if (relu) { v[0] = relu_f(v[0]); v[1] = relu_f(v[1]); v[2] = relu_f(v[2]); v[3] = relu_f(v[3]); }
     Vec4<DT>::store(out + (m * out_ld + c) * ES, v);
 }
 

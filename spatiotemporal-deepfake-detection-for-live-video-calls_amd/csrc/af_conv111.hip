@@ -37,23 +37,37 @@ struct C111Args {
     int tiles;           // position tiles
 };
 
-template <int DT, int KS1, int KS2, bool TPOOL, bool RES>
+// WC = output channels per wave: 64 (4 channel groups x 2 position halves) or, for K = 256 where 64 channels of
+// weights would not fit the registers next to two residual sets, 32 (8 channel groups, every wave all 128 positions).
+template <int DT, int KS1, int KS2, bool TPOOL, bool RES, int WC>
 __global__ __launch_bounds__(512, 1) void conv111_kernel(const C111Args a) {
     typedef Elem<DT> E;
     constexpr int EPC = E::EPC, ES = 16 / EPC;
     static_assert(EPC == 8, "16-bit storage types only");
-    constexpr int KS = KS1 + KS2, BM = 128, TN = 4;
+    static_assert(WC == 64 || (WC == 32 && !TPOOL), "wave columns of 64 or 32 channels; the pooled tile order assumes 64");
+    constexpr int KS = KS1 + KS2, BM = 128, TN = WC / 16;
+    constexpr int NWN = 256 / WC, NWM = 8 / NWN, WPOS = BM / NWM, MT = WPOS / 16;   // wave grid; positions, m-tiles per wave
     constexpr int SLAB = BM * 128, STAGE = KS * SLAB;  // bytes: one 64-channel K slab of the tile; one ring slot
-    constexpr int PROW = 64 + 4;                       // patch row stride in floats (pad: conflict-free b128 writes)
+    constexpr int PROW = WC + 4;                       // patch row stride in floats (pad: conflict-free b128 writes)
+    constexpr int LPR = WC / 8, RPI = 64 / LPR, ITS = 16 / RPI;   // epilogue: lanes per row, rows per instruction, instructions per m-tile
 
     extern __shared__ uint4 smem[];
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int frow = lane & 15, fg = lane >> 4;
-    const int wn = wave & 3, wm = wave >> 2;           // channel group, position half
+    const int wn = wave % NWN, wm = wave / NWN;        // channel group, position part
     float* patch = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + 2 * STAGE) + wave * (16 * PROW);
-    const int col = blockIdx.x % a.ncol, first = blockIdx.x / a.ncol, stride = gridDim.x / a.ncol;
+    // workgroup -> (channel column, tile stream).  Consecutive workgroup ids go round the 8 XCDs, each with its own
+    // L2: the columns of one stream (they read the same activation tiles at the same time) are put on ONE XCD, so the
+    // tile comes from HBM once and from that L2 ncol - 1 times (measured before: s3 `c` fetched its activations twice).
+    int col = blockIdx.x % a.ncol, first = blockIdx.x / a.ncol;
+    const int stride = gridDim.x / a.ncol;
+    if (gridDim.x % (8 * a.ncol) == 0) {
+        const int xcd = blockIdx.x & 7, y = blockIdx.x >> 3;
+        col = y % a.ncol;
+        first = xcd + 8 * (y / a.ncol);
+    }
 
     // tile row r -> position offset from the tile origin.  plain: r.  tpool: r = (half b, tile j, lane row fr) is
     // pixel b*32 + (j&1)*16 + fr of frame j>>1.
@@ -64,7 +78,7 @@ __global__ __launch_bounds__(512, 1) void conv111_kernel(const C111Args a) {
     uint4 wreg[TN][2 * KS];
 #pragma unroll
     for (int i = 0; i < TN; ++i) {
-        const long long ch = col * 256 + wn * 64 + i * 16 + frow;
+        const long long ch = col * 256 + wn * WC + i * 16 + frow;
 #pragma unroll
         for (int k = 0; k < 2 * KS1; ++k)
             wreg[i][k] = *reinterpret_cast<const uint4*>(a.w + (ch * a.Cin + k * 32 + fg * 8) * ES);
@@ -73,13 +87,13 @@ __global__ __launch_bounds__(512, 1) void conv111_kernel(const C111Args a) {
             wreg[i][2 * KS1 + k] = *reinterpret_cast<const uint4*>(a.w2 + (ch * a.Cin2 + k * 32 + fg * 8) * ES);
     }
 
-    // ---- epilogue geometry: lane = (row rr of 8, 8 channels at cc) of a 16-row patch
-    const int rr = lane >> 3, cc = (lane & 7) * 8;
-    const int ch0 = col * 256 + wn * 64 + cc;
+    // ---- epilogue geometry: lane = (row rr of RPI, 8 channels at cc) of a 16-row patch
+    const int rr = lane / LPR, cc = (lane % LPR) * 8;
+    const int ch0 = col * 256 + wn * WC + cc;
     // BN scale / shift of the column's 256 channels live in LDS (registers are what this kernel is short of)
     float* bn = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + 2 * STAGE) + 8 * (16 * PROW);
     if (tid < 256) { bn[tid] = a.scale[col * 256 + tid]; bn[256 + tid] = a.shift[col * 256 + tid]; }
-    const float* bnl = bn + wn * 64 + cc;                // this lane's 8 channels
+    const float* bnl = bn + wn * WC + cc;                // this lane's 8 channels
 
     // ---- producer: per-lane source offsets of the 2 DMA pieces (8 rows each) this wave brings in per K slab
     const int drow = lane >> 3, chunk = (lane & 7) ^ drow;
@@ -120,14 +134,14 @@ __global__ __launch_bounds__(512, 1) void conv111_kernel(const C111Args a) {
                     blds16(row_live(xrow + 64 * i, live) ? x2off : kOutOfRange, d2, s * 128 + i * half2_off, base + (KS1 + s) * SLAB + i * (64 * 128));
         }
     };
-    // residual / output rows of a tile in epilogue order: k = (j, it) is tile row wm*64 + j*16 + it*8 + rr, channels
+    // residual / output rows of a tile in epilogue order: k = (j, it) is tile row wm*WPOS + j*16 + it*RPI + rr, channels
     // ch0 .. ch0+7.  Buffer addressing from the tile's origin: one per-lane offset (row 0 of the lane) plus a per-k
     // scalar, so no 64-bit address lives in a register across the loop; residual rows that do not exist get kOutOfRange
     // (the load returns zeros).
-    const int row0 = wm * 64 + rr;
+    const int row0 = wm * WPOS + rr;
     const unsigned res_lane = (unsigned)((row_off(row0) * a.Cout + ch0) * ES);
     const unsigned out_lane = (unsigned)(((long long)(TPOOL ? row_pixel(row0) : row0) * a.out_ld + ch0) * ES);
-    auto k_row = [&](int k) { return (k >> 1) * 16 + (k & 1) * 8; };                 // tile row of k relative to row0
+    auto k_row = [&](int k) { return (k / ITS) * 16 + (k % ITS) * RPI; };             // tile row of k relative to row0
     auto res_soff = [&](int k) { return (int)((row_off(k_row(k)) * a.Cout) * ES); };  // (row_off is additive over these bits)
     auto out_soff = [&](int k) { return (int)(((long long)(TPOOL ? row_pixel(k_row(k)) : k_row(k)) * a.out_ld) * ES); };
     auto load_residual = [&](int tile, u32x4 (&r)[8]) {
@@ -171,12 +185,12 @@ __global__ __launch_bounds__(512, 1) void conv111_kernel(const C111Args a) {
         // first output position of the tile (pooled: (clip, frame pair) * HW + first pixel = half the origin's frame index)
         const long long opos = TPOOL ? (o - o % a.HW) / 2 + o % a.HW : o;
         char* obase = a.out + opos * a.out_ld * ES;
-        const uint4* xs = smem + slot * (STAGE / 16) + (wm * 64 + frow) * 8;
+        const uint4* xs = smem + slot * (STAGE / 16) + (wm * WPOS + frow) * 8;
 
-        // the wave's 64 positions go in two passes of 2 accumulator tiles (registers: the weights and two residual sets
-        // stay live); tpool: a pass is the two frames (tiles h, h + 2) of 16 pixels
+        // the wave's positions go in passes of 2 accumulator tiles (registers: the weights and two residual sets stay
+        // live); tpool: a pass is the two frames (tiles h, h + 2) of 16 pixels
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < MT / 2; ++h) {
             f32x4 acc[TN][2];
 #pragma unroll
             for (int i = 0; i < TN; ++i) { acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -193,7 +207,7 @@ __global__ __launch_bounds__(512, 1) void conv111_kernel(const C111Args a) {
             }
 
             // ---- epilogue: 16 positions at a time through the wave's patch
-            float keep[2][8];                            // tpool: frame 0 of the pixel rows, waiting for frame 1
+            float keep[ITS][8];                          // tpool: frame 0 of the pixel rows, waiting for frame 1
 #pragma unroll
             for (int jl = 0; jl < 2; ++jl) {
                 const int j = TPOOL ? h + 2 * jl : 2 * h + jl;
@@ -202,8 +216,8 @@ __global__ __launch_bounds__(512, 1) void conv111_kernel(const C111Args a) {
                     *reinterpret_cast<f32x4*>(patch + frow * PROW + i * 16 + fg * 4) = acc[i][jl];
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                for (int it = 0; it < 2; ++it) {
-                    const int prow = it * 8 + rr, row = wm * 64 + j * 16 + prow;
+                for (int it = 0; it < ITS; ++it) {
+                    const int prow = it * RPI + rr, row = wm * WPOS + j * 16 + prow;
                     float v[8];
 #pragma unroll
                     for (int e = 0; e < 8; e += 4) {
@@ -212,14 +226,14 @@ __global__ __launch_bounds__(512, 1) void conv111_kernel(const C111Args a) {
                         v[e] = r[0]; v[e + 1] = r[1]; v[e + 2] = r[2]; v[e + 3] = r[3];
                     }
                     if (RES) {
-                        const uint4 rraw = __builtin_bit_cast(uint4, rcur[j * 2 + it]);
+                        const uint4 rraw = __builtin_bit_cast(uint4, rcur[j * ITS + it]);
                         const typename E::type* re = reinterpret_cast<const typename E::type*>(&rraw);
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] += E::to_f32(re[e]);
                     }
                     if (a.relu) {
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                        for (int e = 0; e < 8; ++e) v[e] = relu_f(v[e]);
                     }
                     if (TPOOL && jl == 0) {
 #pragma unroll
@@ -238,7 +252,7 @@ __global__ __launch_bounds__(512, 1) void conv111_kernel(const C111Args a) {
                     // compiler schedules the next VALU write of the data registers right behind it, and on gfx950 the store
                     // then reads the overwritten dword - measured; it knows the hazard only for immediate offsets)
                     if (row_live(row, live))
-                        __builtin_nontemporal_store(__builtin_bit_cast(u32x4, ov), reinterpret_cast<u32x4*>(obase + out_soff(j * 2 + it) + out_lane));
+                        __builtin_nontemporal_store(__builtin_bit_cast(u32x4, ov), reinterpret_cast<u32x4*>(obase + out_soff(j * ITS + it) + out_lane));
                 }
                 __builtin_amdgcn_wave_barrier();
             }
@@ -246,17 +260,17 @@ __global__ __launch_bounds__(512, 1) void conv111_kernel(const C111Args a) {
     }
 }
 
-template <int DT, int KS1, int KS2, bool TPOOL, bool RES>
+template <int DT, int KS1, int KS2, bool TPOOL, bool RES, int WC = 64>
 static int launch111(const C111Args& a, int blocks, hipStream_t stream) {
-    const int lds = 2 * (KS1 + KS2) * 128 * 128 + 8 * 16 * (64 + 4) * 4 + 2 * 256 * 4;
+    const int lds = 2 * (KS1 + KS2) * 128 * 128 + 8 * 16 * (WC + 4) * 4 + 2 * 256 * 4;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv111_kernel<DT, KS1, KS2, TPOOL, RES>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv111_kernel<DT, KS1, KS2, TPOOL, RES, WC>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return set_error(AF_ERR_LAUNCH, "conv111: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv111_kernel<DT, KS1, KS2, TPOOL, RES>), dim3(blocks), dim3(512), lds, stream, a);
+    hipLaunchKernelGGL((conv111_kernel<DT, KS1, KS2, TPOOL, RES, WC>), dim3(blocks), dim3(512), lds, stream, a);
     AF_CHECK_LAUNCH("conv111_kernel");
     return AF_OK;
 }
@@ -280,7 +294,7 @@ static long long conv111_tiles(const af_conv_desc* d, const af_conv_desc* d2, in
     if (d2) {
         if (d->cin != 64 || d2->cin != 64 || d->tpool) return 0;
         if (d2->st != 1 || d2->sh != 1 || d2->sw != 1 || d2->t != d->t || d2->h != d->h || d2->w != d->w) return 0;
-    } else if (d->cin != 64 && d->cin != 128) return 0;
+    } else if (d->cin != 64 && d->cin != 128 && d->cin != 256) return 0;
     if (d->tpool && (d->cin != 64 || d->t % 2 != 0)) return 0;
     const long long hw = (long long)d->h * d->w;
     if ((hw + 128) * 128 * 2 * 2 >= (1LL << 31)) return 0;                 // 32-bit row offsets inside a tile
@@ -315,6 +329,9 @@ int conv111_run(const af_conv_desc* d, const void* in, const void* w_packed, con
     if (d2) return AF_C111(1, 1, false, false);
     if (d->tpool) return residual ? AF_C111(1, 0, true, true) : AF_C111(1, 0, true, false);
     if (d->cin == 64) return residual ? AF_C111(1, 0, false, true) : AF_C111(1, 0, false, false);
+    if (d->cin == 256)     // 32-channel wave columns: the weights of 64 channels x 256 would not fit the registers
+        return residual ? (bf ? launch111<AF_BF16, 4, 0, false, true, 32>(a, blocks, stream) : launch111<AF_F16, 4, 0, false, true, 32>(a, blocks, stream))
+                        : (bf ? launch111<AF_BF16, 4, 0, false, false, 32>(a, blocks, stream) : launch111<AF_F16, 4, 0, false, false, 32>(a, blocks, stream));
     return residual ? AF_C111(2, 0, false, true) : AF_C111(2, 0, false, false);
 #undef AF_C111
 }

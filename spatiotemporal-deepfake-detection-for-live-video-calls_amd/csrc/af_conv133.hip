@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256, 1) void conv133_c64_kernel(const C133Args a) {
 #pragma unroll
             for (int i = 0; i < NT4; ++i) {
                 f32x4 v = acc[i][k] * sc[i] + sf[i];
-                v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+                v[0] = relu_f(v[0]); v[1] = relu_f(v[1]); v[2] = relu_f(v[2]); v[3] = relu_f(v[3]);
                 const int ch = i * 16 + fg * 4;                             // 4 channels = 8 bytes: half a 16-byte chunk
                 Vec4<DT>::store(otile + row * 128 + (((ch >> 3) ^ (row & 7)) << 4) + (ch & 4) * 2, v);
             }

@@ -141,7 +141,7 @@ __global__ __launch_bounds__(512, 2) void conv311_kernel(const C311Args a) {
 #pragma unroll
             for (int i = 0; i < TN; ++i) {
                 f32x4 v = acc[i][j] * sc[i] + sf[i];
-                if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                if (a.relu) { v[0] = relu_f(v[0]); v[1] = relu_f(v[1]); v[2] = relu_f(v[2]); v[3] = relu_f(v[3]); }
                 Vec4<DT>::store(reinterpret_cast<char*>(patch + frow * PROW + i * 16 + fg * 4), v);
                 acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
             }

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const SmallArgs a) {
                 if (m < a.M && ch < a.Cout) {
                     f32x4 v = acc[i][j] * sc[i] + sf[i];
                     if (a.res) v += Vec4<DT>::load(a.res + (m * a.Cout + ch) * 2);
-                    if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                    if (a.relu) { v[0] = relu_f(v[0]); v[1] = relu_f(v[1]); v[2] = relu_f(v[2]); v[3] = relu_f(v[3]); }
                     Vec4<DT>::store(a.out + (m * a.out_ld + ch) * 2, v);
                 }
             }

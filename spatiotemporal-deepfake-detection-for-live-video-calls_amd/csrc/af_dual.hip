@@ -291,7 +291,7 @@ __global__ void gated_moe_kernel(const float* z_rgb, const float* z_dual, const 
     float s = w2[hidden];
     for (int j = 0; j < hidden; ++j) {
         const float hj = fmaf(W1[3 * j + 2], d, fmaf(W1[3 * j + 1], b, fmaf(W1[3 * j], a, b1[j])));
-        s = fmaf(w2[j], fmaxf(hj, 0.f), s);
+        s = fmaf(w2[j], relu_f(hj), s);
     }
     const float gate = 1.f / (1.f + expf(-s));
     const float pr = 1.f / (1.f + expf(-a / fmaxf(w[0], 1.0f)));

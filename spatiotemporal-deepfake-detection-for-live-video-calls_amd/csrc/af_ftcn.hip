@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void tstem_kernel(const TStemArgs a) {
                 for (int e = 0; e < 4; ++e) v[e] = (y[e] > v[e] || y[e] != y[e]) ? y[e] : v[e];
             }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = v[e] != v[e] ? v[e] : fmaxf(v[e], 0.f);
+            for (int e = 0; e < 4; ++e) v[e] = relu_f(v[e]);
             if (live) Vec4<DT>::store(a.out + (opix * 64 + i * 16 + fg * 4) * ES, v);
         }
     }

@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const StemArgs a) {
             const long long m = m0 + j * 16 + frow;
             if (m < a.M && ch < a.cout) {
                 f32x4 v = acc[i][j] * sc + sf;
-                v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+                v[0] = relu_f(v[0]); v[1] = relu_f(v[1]); v[2] = relu_f(v[2]); v[3] = relu_f(v[3]);
                 Vec4<DT>::store(a.out + (m * a.cout + ch) * ES, v);
             }
         }

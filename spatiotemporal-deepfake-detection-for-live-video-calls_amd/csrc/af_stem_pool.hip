@@ -134,9 +134,9 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const StemPoolArgs a)
                 f32x4 v0 = acc[0][i] * sc[i] + sf[i], v1 = acc[1][i] * sc[i] + sf[i];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    v0[e] = fmaxf(v0[e], 0.f);
-                    v1[e] = odd_ok ? fmaxf(v1[e], 0.f) : 0.f;
-                    const float m = fmaxf(fmaxf(prev[i][e], v0[e]), v1[e]);
+                    v0[e] = relu_f(v0[e]);
+                    v1[e] = odd_ok ? relu_f(v1[e]) : 0.f;
+                    const float m = max_nan(max_nan(prev[i][e], v0[e]), v1[e]);
                     prev[i][e] = v1[e];
                     v0[e] = m;
                 }
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const StemPoolArgs a)
                         const uint4 raw = *reinterpret_cast<const uint4*>(line + c * COUT + ch);
                         const elem_t* pe = reinterpret_cast<const elem_t*>(&raw);
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], E::to_f32(pe[e]));
+                        for (int e = 0; e < 8; ++e) m[e] = max_nan(m[e], E::to_f32(pe[e]));
                     }
                 }
                 uint4 o;

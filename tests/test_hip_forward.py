@@ -216,3 +216,25 @@ def test_small_network_vs_oracle_all_dtypes():
         err = (got - want).abs().max().item()
         print("small net", dtype, "max|d| %.3e" % err, "logits", want.flatten().tolist())
         assert err <= tol, (dtype, err)
+
+
+def test_non_finite_pixel_gives_nan_logit_like_reference():
+    """A NaN pixel must not turn into a plausible score: in the reference it survives Conv3d, eval BN, ReLU (clamp_min keeps
+    NaN), MaxPool3d and AvgPool3d and the clip's logit is NaN; the other clips of the batch are untouched.  Same shrunken
+    network as above (every conv kernel family is on the path); the oracle states the expectation."""
+    clip_size, size = 8, 64
+    from af_mi355x.arch import i3d_r50_spec
+    sd = synth.synthetic_state_dict(i3d_r50_spec(clip_size, size), seed=5)
+    u8 = synth.synthetic_clips_u8(3, seed=9, kind="smooth", num_frames=clip_size, size=size)
+    x = synth.normalize_like_callers(u8)
+    x[1, 2, 3, 17, 40] = float("nan")
+    want = oracle.forward(sd, x, num_frames=clip_size, crop=size)
+    assert torch.isnan(want[1]).all() and torch.isfinite(want[[0, 2]]).all()
+    for dtype, tol in (("f32", 1e-4), ("f16", 1e-2), ("bf16", 6e-2)):
+        clf = Classifier(clip_size=clip_size, precision=dtype, crop_size=size)
+        clf.network.load_state_dict(sd)
+        clf = clf.to("cuda").eval()
+        with torch.inference_mode():
+            got = clf(x.cuda())["final_output"].cpu()
+        assert torch.isnan(got[1]).all(), (dtype, got)
+        assert (got[[0, 2]] - want[[0, 2]]).abs().max().item() <= tol, (dtype, got, want)
