@@ -269,6 +269,31 @@ def test_projection_shortcut_stream_at_size(dtype):
     assert (got - want).abs().max().item() <= tol * want.abs().max().item()
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_projection_shortcut_256_tile(dtype):
+    """s4's first block: c (256 -> 1024) + strided shortcut (512 -> 1024, stride (1,2,2)) as one launch on the 256x256 tile
+    (12 K-steps over two inputs, second one gathered at stride 2)."""
+    n, t, hw, cin, cin2, cout, seed = 4, 16, 14, 256, 512, 1024, 1212
+    lay = []
+    for nm, ci in (("c", cin), ("b1", cin2)):
+        lay += [(nm + ".weight", (cout, ci, 1, 1, 1), "float32"), (nm + "_bn.weight", (cout,), "float32"), (nm + "_bn.bias", (cout,), "float32"),
+                (nm + "_bn.running_mean", (cout,), "float32"), (nm + "_bn.running_var", (cout,), "float32")]
+    sd = synth.fill_layout(lay, seed)
+    x = synth.synthetic_tensor((n, cin, t, hw, hw), seed)
+    x2 = synth.synthetic_tensor((n, cin2, t, 2 * hw, 2 * hw), seed + 1)
+    if dtype != "f32":
+        x, x2 = x.to(hh.TORCH_DT[dtype]).float(), x2.to(hh.TORCH_DT[dtype]).float()
+    sdd = {k: v.double() for k, v in sd.items()}
+    want = F.relu(oracle.conv_bn_act(x.double(), sdd["c.weight"], sdd, "c_bn", (1, 1, 1), (0, 0, 0), False) +
+                  oracle.conv_bn_act(x2.double(), sdd["b1.weight"], sdd, "b1_bn", (1, 2, 2), (0, 0, 0), False))
+    got = hh.conv_dual(hh.to_ndhwc(x, dtype), sd["c.weight"], hh.fold_bn(sd, "c_bn"), hh.to_ndhwc(x2, dtype), sd["b1.weight"],
+                       hh.fold_bn(sd, "b1_bn"), (1, 2, 2), dtype)
+    assert hh.conv_dual.last_variant == 6, hh.conv_dual.last_variant
+    got = hh.to_ncdhw(got).double()
+    tol = {"f32": 5e-6, "bf16": 2.4e-2}[dtype]          # bf16: BN scales folded into the packed weights (one more rounding)
+    assert (got - want).abs().max().item() <= tol * want.abs().max().item()
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("cin,cout,dims,relu", [(128, 128, (2, 3, 8, 10), True),       # pooled `b` conv (64x128 tile: 4 pooled rows per patch)
                                                 (256, 512, (1, 4, 12, 6), False),      # pooled projection shortcut
