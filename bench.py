@@ -131,6 +131,83 @@ def bench_dualrun(args, rank, world, dev):
         dist.destroy_process_group()
 
 
+def bench_aligner(args, rank, world, dev):
+    """SURVEY 8f rank 5 on its own: FasterCropAlignXRay's warps for `--batch` clips of 32 tracked crops (~420x420) -> 224x224
+    per GPU; value = clips/s with the crops and the fitted transforms already resident (the warp launches only); the
+    host-inclusive rate (numpy fit + pinned upload + launch + sync) is reported next to it.  Not the BASELINE metric."""
+    import numpy as np
+    from af_mi355x import aligner
+    B, size = args.batch, 224
+    al = aligner.FasterCropAlignXRay(size)
+    clips = [aligner.synthetic_clip(32, seed=2026 + 100 * rank + i) for i in range(B)]
+    staged = []
+    for infos, crops in clips:
+        boxes = np.array([b for _, _, _, b in infos])
+        lt = boxes[:, :2].min(0)
+        w, h = boxes[:, 2:].max(0) - lt
+        diff = boxes[:, :2] - lt[None]
+        tfm, _ = aligner.estimate_batch_transform(np.array([l5 for _, l5, _, _ in infos]) + diff[:, None, :], al.std_points)
+        dcrops, offs, host = al.stage_crops(crops, dev)
+        staged.append((dcrops, offs, [c.shape for c in crops], diff, int(h), int(w), tfm, host))
+    out = torch.empty((B, 32, size, size, 3), dtype=torch.uint8, device=dev)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    def step():
+        for i, (dcrops, offs, shapes, diff, h, w, tfm, _) in enumerate(staged):
+            al.launch_warps(dcrops, offs, shapes, diff, h, w, tfm, out[i])
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    crop_bytes = sum(int(np.prod(s)) for st in staged for s in st[2])
+    alg = crop_bytes + out.numel()                                   # every crop byte once + the aligned clip
+    line = {"metric": "clips/sec (aligner: 32 crops -> 224x224)", "value": round(world * B * args.steps / dt, 2), "unit": "clips/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "FasterCropAlignXRay warps, batch=%d clips/GPU x 32 crops (380-460 px) -> 224x224x3 uint8, "
+                                   "crops and fitted transforms resident in HBM" % B,
+                       "global_batch": world * B, "parallelism": "dp%d" % world},
+            "roofline": {"bound": "hbm", "kernel": "warp_affine_clip_kernel", "launches_per_step": B,
+                         "avg_launch_us": round(1e6 * dt / args.steps / B, 2), "achieved": round(alg / (dt / args.steps) / 1e9, 2),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+                         "traffic": None, "algorithmic_bytes_per_launch": alg // B,
+                         "note": "launch-bound at this size (a clip is ~22 MB): back-to-back launches, wall clock"}}
+    t0 = time.perf_counter()
+    reps = 5
+    for _ in range(reps):
+        for infos, crops in clips:
+            al(infos, crops, device_output=True)
+    line["host_inclusive_clips_per_s"] = round(B * reps / (time.perf_counter() - t0), 2)
+    if rank == 0 and world == 1 and args.cpu_clips > 0:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import aligner_oracle
+        t0 = time.perf_counter()
+        _, ref = aligner_oracle.crop_align([(a, b.copy(), c.copy(), d.copy()) for a, b, c, d in clips[0][0]], clips[0][1], size=size)
+        tc = time.perf_counter() - t0
+        line["cpu_baseline"] = {"value": round(1.0 / tc, 2), "unit": "clips/s", "cores": 1, "kind": "port",
+                                "sample": "1 clip (32 crops), numpy restatement of the fit + fixed-point warp, 1 thread"}
+        line["bytes_differing_vs_cpu"] = int((out[0].cpu().numpy() != ref).sum())
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -139,7 +216,7 @@ def main():
     ap.add_argument("--batch", type=int, default=16, help="clips per GPU")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--cpu-clips", type=int, default=4, help="clips in the CPU baseline sample (0 = skip)")
-    ap.add_argument("--model", default="i3d", choices=["i3d", "slowfast", "ftcn_tt", "dualrun"],
+    ap.add_argument("--model", default="i3d", choices=["i3d", "slowfast", "ftcn_tt", "dualrun", "aligner"],
                     help="i3d = the i3d_ori plugin (BASELINE metric); slowfast = the two-pathway SlowFast-R50, ftcn_tt = the "
                          "reference's second plugin (next rows of SURVEY 8f)")
     ap.add_argument("--no-roofline", action="store_true")
@@ -163,6 +240,8 @@ def main():
 
     if args.model == "dualrun":
         return bench_dualrun(args, rank, world, dev)
+    if args.model == "aligner":
+        return bench_aligner(args, rank, world, dev)
     if args.model == "slowfast":
         from af_mi355x.arch import slowfast_r50_spec
         from af_mi355x.classifier import SlowFast8x8

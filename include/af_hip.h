@@ -221,6 +221,26 @@ int af_dual_head(const float* z, const float* weights, int clips, int n, float* 
 int af_gated_moe(const float* z_rgb, const float* z_dual, const float* weights, int hidden, int n, float* z, float* gate,
                  void* stream);
 
+/* ---- clip aligner --------------------------------------------------- */
+
+/* Replaces the per-frame loop of FasterCropAlignXRay.__call__ / process_single
+ * (altfreezing/test_tools/faster_crop_align_xray.py:62-66, 75-88):
+ *     new_image = zeros((h, w, 3), uint8); new_image[y:y+ih, x:x+iw] = image; cv2.warpAffine(new_image, tfm, (size, size))
+ * for the n_frames frames of one clip in one launch.  `crops`: device buffer holding the frames' HxWx3 uint8 crops
+ * (tightly packed rows), frame i at byte `frames[i].offset`; `frames` (HOST memory, copied into the launch): crop size
+ * (ih, iw) and paste position (x, y) on the h x w canvas - a crop that does not fit the canvas is an error, as numpy's
+ * slice assignment is in the reference; `tfm`: the forward 2x3 matrix (host, row-major doubles) as passed to
+ * cv2.warpAffine; `out`: device (n_frames, size, size, 3) uint8 - the layout af_pack_input_u8 takes.
+ * Arithmetic: OpenCV's fixed-point INTER_LINEAR / BORDER_CONSTANT(0) warp (see csrc/af_align.hip). */
+#define AF_ALIGN_MAX_FRAMES 64
+typedef struct af_align_frame {
+    int64_t offset;
+    int32_t ih, iw;
+    int32_t x, y;
+} af_align_frame;
+int af_warp_affine_clip_u8(const void* crops, const af_align_frame* frames, int n_frames, int canvas_h, int canvas_w,
+                           const double* tfm, int size, void* out, void* stream);
+
 /* ---- whole-forward op list ------------------------------------------------------------ */
 
 enum af_op_kind { AF_OP_STEM = 0, AF_OP_CONV = 1, AF_OP_MAXPOOL = 2, AF_OP_HEAD = 3,

@@ -461,6 +461,54 @@ def gen_dualrun():
     np.savez_compressed(os.path.join(GOLD, "f7_dualrun.npz"), **out)
 
 
+def synthetic_aligner_case(rng, frames, size, mirrored=False):
+    """per-frame (ldm5, ldm68, big box): a face whose 5 points are the aligner's standard points under a random similarity
+    (+ per-frame jitter), boxes of slightly different origin / size per frame, as the trackers upstream produce"""
+    std = np.array([[85.82991, 115.7792], [169.0532, 114.3381], [127.574, 167.0006], [90.6964, 204.7014], [167.3069, 203.3733]])
+    ang, sc = rng.uniform(-0.5, 0.5), rng.uniform(0.6, 1.6)
+    rot = np.array([[np.cos(ang), -np.sin(ang)], [np.sin(ang), np.cos(ang)]]) * sc
+    infos = []
+    for _ in range(frames):
+        p5 = std @ rot.T + rng.uniform(40, 60, size=(1, 2)) + rng.normal(0, 1.5, size=(5, 2))
+        if mirrored:
+            p5[:, 0] = 400 - p5[:, 0]
+        p68 = p5.mean(0, keepdims=True) + rng.normal(0, 40 * sc, size=(68, 2))
+        x0, y0 = rng.integers(100, 140, size=2)
+        bw, bh = rng.integers(380, 460, size=2)
+        infos.append((None, p5, p68, np.array([x0, y0, x0 + bw, y0 + bh], dtype=np.int64)))
+    return infos
+
+
+def gen_aligner():
+    """F8: the similarity fit / landmark transform of the clip aligner (test_tools/warp_for_xray.py,
+    test_tools/faster_crop_align_xray.py with images=None) - pure numpy in the reference.  Both files `import cv2` at the top;
+    OpenCV is absent here, so an EMPTY stand-in module satisfies the import and is never called (cv2.warpAffine, the only
+    use, is not on this path and stays unpinned: oracle/aligner_oracle.py header)."""
+    import importlib
+    import types
+    sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+    pkg = types.ModuleType("ref_test_tools")
+    pkg.__path__ = [os.path.join(ref_import.ALTFREEZING_DIR, "test_tools")]      # the package's own __init__ is not run
+    sys.modules["ref_test_tools"] = pkg
+    fca = importlib.import_module("ref_test_tools.faster_crop_align_xray")
+    wfx = importlib.import_module("ref_test_tools.warp_for_xray")
+    rng = np.random.default_rng(20260104)
+    out = {"std_points_256": wfx.std_points_256}
+    for tag, frames, size, mirrored in (("t32_224", 32, 224, False), ("t1_256", 1, 256, False), ("t8_mirrored", 8, 224, True)):
+        infos = synthetic_aligner_case(rng, frames, size, mirrored)
+        out[tag + "_ldm5"] = np.array([i[1] for i in infos])
+        out[tag + "_ldm68"] = np.array([i[2] for i in infos])
+        out[tag + "_boxes"] = np.array([i[3] for i in infos])
+        al = fca.FasterCropAlignXRay(size, return_ldm5=True)
+        t5, t68 = al([(a, b.copy(), c.copy(), d.copy()) for a, b, c, d in infos], images=None)
+        boxes = out[tag + "_boxes"]
+        diff = boxes[:, :2] - boxes[:, :2].min(0)[None]
+        tfm, trans = wfx.estimiate_batch_transform(out[tag + "_ldm5"] + diff[:, None, :], tgt_pts=al.std_points)
+        out[tag + "_t5"], out[tag + "_t68"], out[tag + "_tfm"], out[tag + "_trans"] = t5, t68, tfm, trans
+        print("F8 aligner", tag, "tfm", np.round(tfm, 4).tolist())
+    np.savez_compressed(os.path.join(GOLD, "f8_aligner.npz"), **out)
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.manual_seed(0)
@@ -472,10 +520,14 @@ def main():
     gen_f1_f2(clf)
     gen_slowfast()
     gen_dualrun()
+    gen_aligner()
 
 
 if __name__ == "__main__":
-    if "--dualrun" in sys.argv:
+    if "--aligner" in sys.argv:
+        os.makedirs(GOLD, exist_ok=True)
+        gen_aligner()
+    elif "--dualrun" in sys.argv:
         os.makedirs(GOLD, exist_ok=True)
         torch.set_num_threads(8)
         gen_dualrun()

@@ -21,6 +21,13 @@ class ConvDesc(C.Structure):
         "to", "ho", "wo", "relu", "dtype", "tpool")]
 
 
+class AlignFrame(C.Structure):
+    _fields_ = [("offset", C.c_int64), ("ih", C.c_int32), ("iw", C.c_int32), ("x", C.c_int32), ("y", C.c_int32)]
+
+
+ALIGN_MAX_FRAMES = 64
+
+
 class PoolDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "n", "t", "h", "w", "c", "kt", "kh", "kw", "st", "sh", "sw", "pt", "ph", "pw", "to", "ho", "wo", "dtype",
@@ -80,6 +87,8 @@ ABI = {
     "af_dual_branch_encoders": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_void_p,
                                            C.c_void_p] + [C.c_int] * 6 + [C.c_float, C.c_void_p, C.c_int, C.c_void_p]),
     "af_gated_moe": (C.c_int, [C.c_void_p] * 3 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "af_warp_affine_clip_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_int,
+                                         C.c_void_p, C.c_void_p]),
     "af_dual_head": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "af_run_ops": (C.c_int, [C.POINTER(Op), C.c_int, C.c_void_p]),
     "af_run_ops_timed": (C.c_int, [C.POINTER(Op), C.c_int, C.c_void_p, C.POINTER(C.c_float)]),

@@ -177,3 +177,28 @@ def test_abi_rejects_bad_arguments_without_a_gpu():
     assert b"null" in _lib.lib.af_last_error()
     assert _lib.lib.af_packed_conv_weight_bytes(64, 64, 1, 3, 3, 1) == 64 * 64 * 9 * 2
     assert _lib.lib.af_stem_input_bytes(1, 32, 224, 224, 0) == 36 * 230 * 232 * 4 * 4
+
+
+def test_aligner_host_fit_matches_reference():
+    """FasterCropAlignXRay's host side (similarity fit over all frames, landmark transform) against the vectors the
+    reference's numpy code produced (tests/golden/f8_aligner.npz), incl. the mirrored clip that takes the reflective
+    solution; the landmark-only call needs neither GPU nor library."""
+    import numpy as np
+    from conftest import load_npz
+    from af_mi355x import aligner
+    g = load_npz("f8_aligner.npz")
+    np.testing.assert_allclose(aligner.STD_POINTS_256, g["std_points_256"], rtol=0, atol=1e-12)
+    for tag, size in (("t32_224", 224), ("t1_256", 256), ("t8_mirrored", 224)):
+        infos = [(None, a.copy(), b.copy(), c.copy()) for a, b, c in zip(g[tag + "_ldm5"], g[tag + "_ldm68"], g[tag + "_boxes"])]
+        t5, t68 = aligner.FasterCropAlignXRay(size, return_ldm5=True)(infos)
+        np.testing.assert_allclose(t5, g[tag + "_t5"], rtol=1e-10, atol=1e-9)
+        np.testing.assert_allclose(t68, g[tag + "_t68"], rtol=1e-10, atol=1e-9)
+        only68 = aligner.FasterCropAlignXRay(size)(infos)
+        np.testing.assert_allclose(only68, g[tag + "_t68"], rtol=1e-10, atol=1e-9)
+        boxes = g[tag + "_boxes"]
+        diff = boxes[:, :2] - boxes[:, :2].min(0)[None]
+        tfm, trans = aligner.estimate_batch_transform(g[tag + "_ldm5"] + diff[:, None, :], aligner.STD_POINTS_256 * size / 256.0)
+        np.testing.assert_allclose(tfm, g[tag + "_tfm"], rtol=1e-10, atol=1e-10)
+        np.testing.assert_allclose(trans, g[tag + "_trans"], rtol=1e-10, atol=1e-10)
+    with pytest.raises(Exception, match="twoUniquePointsReq"):
+        aligner.estimate_batch_transform(g["t1_256_ldm5"], np.zeros((5, 2)))       # rank-deficient targets (cp2tform's error)

@@ -172,3 +172,50 @@ def test_scores_postprocessing():
     assert torch.allclose(oracle.scores(l), torch.sigmoid(l[:, 0]))
     l2 = torch.tensor([[0.0, 1.0]])
     assert torch.allclose(oracle.scores(l2), torch.softmax(l2, 1)[:, 1])
+
+
+ALIGNER_CASES = (("t32_224", 224), ("t1_256", 256), ("t8_mirrored", 224))
+
+
+def _aligner_infos(g, tag):
+    return [(None, l5.copy(), l68.copy(), box.copy()) for l5, l68, box in zip(g[tag + "_ldm5"], g[tag + "_ldm68"], g[tag + "_boxes"])]
+
+
+def test_aligner_similarity_fit_matches_reference():
+    """F8: the clip aligner's similarity fit and landmark transform against the reference's numpy code (incl. the
+    reflective branch of findSimilarity and its in-place reflection of the targets); cv2.warpAffine is not covered by
+    any reference output - the warp restatement is parity-unpinned (oracle/aligner_oracle.py header)."""
+    import aligner_oracle as ao
+    g = load_npz("f8_aligner.npz")
+    np.testing.assert_allclose(ao.STD_POINTS_256, g["std_points_256"], rtol=0, atol=0)
+    for tag, size in ALIGNER_CASES:
+        infos = _aligner_infos(g, tag)
+        t5, t68 = ao.crop_align(infos, None, size=size, return_ldm5=True)
+        np.testing.assert_allclose(t5, g[tag + "_t5"], rtol=1e-10, atol=1e-9)
+        np.testing.assert_allclose(t68, g[tag + "_t68"], rtol=1e-10, atol=1e-9)
+        boxes = g[tag + "_boxes"]
+        diff = boxes[:, :2] - boxes[:, :2].min(0)[None]
+        tfm, trans = ao.estimate_batch_transform(g[tag + "_ldm5"] + diff[:, None, :], ao.STD_POINTS_256 * size / 256.0)
+        np.testing.assert_allclose(tfm, g[tag + "_tfm"], rtol=1e-10, atol=1e-10)
+        np.testing.assert_allclose(trans, g[tag + "_trans"], rtol=1e-10, atol=1e-10)
+    assert g["t8_mirrored_tfm"][0, 0] < 0          # the mirrored case really took the reflective solution
+
+
+def test_aligner_warp_restatement_properties():
+    """size-independent properties of the fixed-point bilinear warp (unpinned against cv2): identity and integer
+    translations reproduce the source exactly with a zero border; a half-pixel shift is the rounded mean of neighbours;
+    the result of a general transform stays within the hull of the 4 taps."""
+    import aligner_oracle as ao
+    rng = np.random.default_rng(5)
+    src = rng.integers(0, 256, size=(40, 52, 3), dtype=np.uint8)
+    ident = np.array([[1.0, 0, 0], [0, 1.0, 0]])
+    out = ao.warp_affine_u8(src, ident, 64)
+    assert (out[:40, :52] == src).all() and (out[40:] == 0).all() and (out[:, 52:] == 0).all()
+    out = ao.warp_affine_u8(src, np.array([[1.0, 0, 7], [0, 1.0, 3]]), 64)
+    assert (out[3:43, 7:59] == src).all() and (out[:3] == 0).all() and (out[:, :7] == 0).all()
+    out = ao.warp_affine_u8(src, np.array([[1.0, 0, 0.5], [0, 1.0, 0]]), 64)          # dst(x) samples src(x - 0.5)
+    want = (src[:, :-1].astype(np.int64) + src[:, 1:].astype(np.int64) + 1) >> 1
+    assert (out[:40, 1:52] == want).all()
+    m = np.array([[0.83, -0.21, 5.3], [0.21, 0.83, -2.7]])
+    out = ao.warp_affine_u8(np.full((30, 30, 3), 200, dtype=np.uint8), m, 48)
+    assert out.max() == 200 and set(np.unique(out)) - {0, 200} != set()                # edges blend towards the border 0
