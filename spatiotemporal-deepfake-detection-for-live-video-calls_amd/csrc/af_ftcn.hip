@@ -56,6 +56,11 @@ __global__ __launch_bounds__(256) void tstem_kernel(const TStemArgs a) {
         sf[i] = *reinterpret_cast<const f32x4*>(a.shift + i * 16 + fg * 4);
     }
     const long long row_b = (long long)a.Wp * PIXB, plane_b = row_b * a.Hp;
+    // 16-bit output: the tile's 16 pooled pixels are 2 KB of CONTIGUOUS NDHWC bytes; the accumulator layout would write
+    // them as 8-byte pieces (32 contiguous bytes per pixel and instruction).  They cross a per-wave LDS patch instead
+    // ([pixel][8 chunks of 16 B], chunk ^= pixel & 7) and leave as two 1-KB wave stores of whole 128-byte rows.
+    __shared__ uint4 patch_all[DT == AF_F32 ? 1 : 4 * 128];
+    char* patch = reinterpret_cast<char*>(patch_all) + (DT == AF_F32 ? 0 : (threadIdx.x >> 6) * 2048);
 
     for (long long tile = wave0; tile < a.tiles; tile += nwaves) {
         const int tw = (int)(tile % a.tiles_w); long long q = tile / a.tiles_w;
@@ -93,6 +98,7 @@ __global__ __launch_bounds__(256) void tstem_kernel(const TStemArgs a) {
         }
         // BN on each window member, 2x2 max (NaN propagates like ATen's max_pool), ReLU, store 4 channels per tile
         const long long opix = ((n * a.T + t) * a.Ho + ph) * a.Wo + pw;
+        const long long opix0 = ((n * a.T + t) * a.Ho + ph) * a.Wo + tw * 16;      // pooled pixel 0 of the tile
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             f32x4 v = acc[0][i] * sc[i] + sf[i];
@@ -104,7 +110,23 @@ __global__ __launch_bounds__(256) void tstem_kernel(const TStemArgs a) {
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = relu_f(v[e]);
-            if (live) Vec4<DT>::store(a.out + (opix * 64 + i * 16 + fg * 4) * ES, v);
+            if (DT == AF_F32) {
+                if (live) Vec4<DT>::store(a.out + (opix * 64 + i * 16 + fg * 4) * ES, v);
+            } else {
+                const int c = i * 2 + (fg >> 1);                        // 16-byte chunk of channels i*16 + fg*4 ..
+                Vec4<DT>::store(patch + frow * 128 + ((c ^ (frow & 7)) * 16) + (fg & 1) * 8, v);
+            }
+        }
+        if (DT != AF_F32) {
+            __builtin_amdgcn_wave_barrier();                            // same-wave LDS ops complete in order
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int p = it * 8 + (lane >> 3), c = lane & 7;
+                const uint4 o = *reinterpret_cast<const uint4*>(patch + p * 128 + ((c ^ (p & 7)) * 16));
+                if (tw * 16 + p < a.Wo)
+                    __builtin_nontemporal_store(__builtin_bit_cast(u32x4, o), reinterpret_cast<u32x4*>(a.out + ((opix0 + p) * 64 + c * 8) * ES));
+            }
+            __builtin_amdgcn_wave_barrier();
         }
     }
 }
