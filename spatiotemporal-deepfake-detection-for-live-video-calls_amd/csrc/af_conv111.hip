@@ -90,10 +90,14 @@ __global__ __launch_bounds__(512, 1) void conv111_kernel(const C111Args a) {
     // ---- epilogue geometry: lane = (row rr of RPI, 8 channels at cc) of a 16-row patch
     const int rr = lane / LPR, cc = (lane % LPR) * 8;
     const int ch0 = col * 256 + wn * WC + cc;
-    // BN scale / shift of the column's 256 channels live in LDS (registers are what this kernel is short of)
-    float* bn = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + 2 * STAGE) + 8 * (16 * PROW);
-    if (tid < 256) { bn[tid] = a.scale[col * 256 + tid]; bn[256 + tid] = a.shift[col * 256 + tid]; }
-    const float* bnl = bn + wn * WC + cc;                // this lane's 8 channels
+    // BN scale / shift of this lane's 8 channels: registers (read from LDS per use they were a third of the kernel's LDS
+    // traffic; the two-pass accumulators left the room)
+    f32x4 sc[2], sf[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        sc[e] = *reinterpret_cast<const f32x4*>(a.scale + ch0 + 4 * e);
+        sf[e] = *reinterpret_cast<const f32x4*>(a.shift + ch0 + 4 * e);
+    }
 
     // ---- producer: per-lane source offsets of the 2 DMA pieces (8 rows each) this wave brings in per K slab
     const int drow = lane >> 3, chunk = (lane & 7) ^ drow;
@@ -222,7 +226,7 @@ __global__ __launch_bounds__(512, 1) void conv111_kernel(const C111Args a) {
 #pragma unroll
                     for (int e = 0; e < 8; e += 4) {
                         const f32x4 t = *reinterpret_cast<const f32x4*>(patch + prow * PROW + cc + e);
-                        const f32x4 r = t * *reinterpret_cast<const f32x4*>(bnl + e) + *reinterpret_cast<const f32x4*>(bnl + 256 + e);
+                        const f32x4 r = t * sc[e >> 2] + sf[e >> 2];
                         v[e] = r[0]; v[e + 1] = r[1]; v[e + 2] = r[2]; v[e + 3] = r[3];
                     }
                     if (RES) {
@@ -262,7 +266,7 @@ __global__ __launch_bounds__(512, 1) void conv111_kernel(const C111Args a) {
 
 template <int DT, int KS1, int KS2, bool TPOOL, bool RES, int WC = 64>
 static int launch111(const C111Args& a, int blocks, hipStream_t stream) {
-    const int lds = 2 * (KS1 + KS2) * 128 * 128 + 8 * 16 * (WC + 4) * 4 + 2 * 256 * 4;
+    const int lds = 2 * (KS1 + KS2) * 128 * 128 + 8 * 16 * (WC + 4) * 4;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv111_kernel<DT, KS1, KS2, TPOOL, RES, WC>),
