@@ -62,10 +62,10 @@ __global__ __launch_bounds__(256) void tstem_kernel(const TStemArgs a) {
     __shared__ uint4 patch_all[DT == AF_F32 ? 1 : 4 * 128];
     char* patch = reinterpret_cast<char*>(patch_all) + (DT == AF_F32 ? 0 : (threadIdx.x >> 6) * 2048);
 
-    for (long long tile = wave0; tile < a.tiles; tile += nwaves) {
-        const int tw = (int)(tile % a.tiles_w); long long q = tile / a.tiles_w;
-        const int ph = (int)(q % a.Ho); q /= a.Ho;
-        const int t = (int)(q % a.T); const long long n = q / a.T;
+    for (unsigned tile = (unsigned)wave0; tile < (unsigned)a.tiles; tile += (unsigned)nwaves) {   // (tiles < 2^31: host-checked)
+        const int tw = (int)(tile % (unsigned)a.tiles_w); unsigned q = tile / (unsigned)a.tiles_w;
+        const int ph = (int)(q % (unsigned)a.Ho); q /= (unsigned)a.Ho;
+        const int t = (int)(q % (unsigned)a.T); const long long n = q / (unsigned)a.T;
         int pw = tw * 16 + frow;                                        // pooled column of this lane
         const bool live = pw < a.Wo;
         if (!live) pw = a.Wo - 1;                                       // ragged last tile: clamped, never stored
@@ -80,20 +80,35 @@ __global__ __launch_bounds__(256) void tstem_kernel(const TStemArgs a) {
         for (int kb = 0; kb < KB; ++kb) {
             // this lane's chunk: TPC consecutive taps starting at tap0; taps >= kt have zero weights and are not read
             const int tap0 = (kb * 4 + fg) * TPC;
+            if (DT == AF_F32) {
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const char* p = px + (m >> 1) * row_b + (m & 1) * PIXB;
-                uint4 b = uint4{0u, 0u, 0u, 0u};
-                if (DT == AF_F32) {
+                for (int m = 0; m < 4; ++m) {
+                    const char* p = px + (m >> 1) * row_b + (m & 1) * PIXB;
+                    uint4 b = uint4{0u, 0u, 0u, 0u};
                     if (tap0 < a.kt) b = *reinterpret_cast<const uint4*>(p + tap0 * plane_b);
-                } else {
-                    uint2 lo = uint2{0u, 0u}, hi = uint2{0u, 0u};
-                    if (tap0 < a.kt) lo = *reinterpret_cast<const uint2*>(p + tap0 * plane_b);
-                    if (tap0 + 1 < a.kt) hi = *reinterpret_cast<const uint2*>(p + (tap0 + 1) * plane_b);
-                    b = uint4{lo.x, lo.y, hi.x, hi.y};
-                }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) Mma<DT>::run(wf[kb][i], b, acc[m][i]);
+                    for (int i = 0; i < 4; ++i) Mma<DT>::run(wf[kb][i], b, acc[m][i]);
+                }
+            } else {
+                // 16-bit: the two horizontal window members are adjacent 8-byte pixels - one 16-byte load (8-byte aligned:
+                // the left padding is odd) per (row, tap) serves both: 4 loads of 256 contiguous bytes per lane group
+                // instead of 8 strided 8-byte ones
+                typedef u32x4 __attribute__((aligned(8))) u32x4_a8;
+                uint4 l[2][2];
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                    for (int tp = 0; tp < 2; ++tp) {
+                        l[dy][tp] = uint4{0u, 0u, 0u, 0u};
+                        if (tap0 + tp < a.kt) l[dy][tp] = __builtin_bit_cast(uint4, *reinterpret_cast<const u32x4_a8*>(px + dy * row_b + (tap0 + tp) * plane_b));
+                    }
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const uint4 &l0 = l[m >> 1][0], &l1 = l[m >> 1][1];
+                    const uint4 b = (m & 1) ? uint4{l0.z, l0.w, l1.z, l1.w} : uint4{l0.x, l0.y, l1.x, l1.y};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) Mma<DT>::run(wf[kb][i], b, acc[m][i]);
+                }
             }
         }
         // BN on each window member, 2x2 max (NaN propagates like ATen's max_pool), ReLU, store 4 channels per tile
@@ -101,15 +116,23 @@ __global__ __launch_bounds__(256) void tstem_kernel(const TStemArgs a) {
         const long long opix0 = ((n * a.T + t) * a.Ho + ph) * a.Wo + tw * 16;      // pooled pixel 0 of the tile
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            f32x4 v = acc[0][i] * sc[i] + sf[i];
+            // max over the window of bn(x) = bn(max x) for a scale >= 0 and bn(min x) for a scale < 0 (x -> x*s + b is
+            // monotonic, so the selected member's image IS the maximum image, bit for bit): one FMA instead of four and
+            // plain 3-input max / min on the raw accumulators; a NaN member (unordered compare) makes the result NaN
+            // like ATen's max_pool.
+            f32x4 v;
 #pragma unroll
-            for (int m = 1; m < 4; ++m) {
-                const f32x4 y = acc[m][i] * sc[i] + sf[i];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = (y[e] > v[e] || y[e] != y[e]) ? y[e] : v[e];
+            for (int e = 0; e < 4; ++e) {
+                const float x0 = acc[0][i][e], x1 = acc[1][i][e], x2 = acc[2][i][e], x3 = acc[3][i][e];
+                float mx, mn;
+                asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mx) : "v"(x0), "v"(x1), "v"(x2));
+                asm("v_max_f32 %0, %1, %2" : "=v"(mx) : "v"(mx), "v"(x3));
+                asm("v_min3_f32 %0, %1, %2, %3" : "=v"(mn) : "v"(x0), "v"(x1), "v"(x2));
+                asm("v_min_f32 %0, %1, %2" : "=v"(mn) : "v"(mn), "v"(x3));
+                const float y = (sc[i][e] >= 0.f ? mx : mn) * sc[i][e] + sf[i][e];
+                const bool nan = __builtin_isunordered(x0, x1) || __builtin_isunordered(x2, x3);
+                v[e] = relu_f(nan ? __builtin_nanf("") : y);
             }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = relu_f(v[e]);
             if (DT == AF_F32) {
                 if (live) Vec4<DT>::store(a.out + (opix * 64 + i * 16 + fg * 4) * ES, v);
             } else {
@@ -256,6 +279,7 @@ extern "C" int af_tstem_conv_bn_pool_relu(const af_conv_desc* d, const void* ste
     a.H = d->h; a.W = d->w; a.Ho = d->ho; a.Wo = d->wo; a.tiles_w = (d->wo + 15) / 16;
     a.tiles = (long long)d->n * d->t * d->ho * a.tiles_w;
     a.t_off = AF_STEM_PAD_T - d->pt; a.kt = d->kt;
+    AF_REQUIRE(a.tiles < (1LL << 31), "tstem: %lld tiles", a.tiles);
     long long blocks = (a.tiles + 4 * 4 - 1) / (4 * 4);                   // ~4 tiles per wave
     if (blocks > 256 * 64) blocks = 256 * 64;
     if (blocks < 1) blocks = 1;

@@ -102,14 +102,19 @@ def test_ftcn_head_known_answer(ftcn_weights):
 @pytest.mark.parametrize("dtype", ["f32", "f16", "bf16"])
 @pytest.mark.parametrize("dims,kt", [((1, 6, 10, 14), 5), ((2, 3, 8, 32), 5), ((1, 4, 6, 8), 3)])
 def test_temporal_stem_vs_oracle(dtype, dims, kt):
-    """Conv3d(3->64,[kt,1,1]) + BN + MaxPool3d((1,2,2)) + ReLU, incl. a ragged last tile (pooled width % 4 != 0)."""
+    """Conv3d(3->64,[kt,1,1]) + BN + MaxPool3d((1,2,2)) + ReLU, incl. a ragged last tile (pooled width % 4 != 0), BN scales of
+    both signs (the kernel pools BEFORE the affine map: max for a non-negative scale, min for a negative one) and a NaN
+    pixel (every pooled output whose window or taps touch it is NaN, like ATen's conv + max_pool; the rest is untouched)."""
     n, t, h, w = dims
     seed = 4242 + kt + w
     lay = [("conv.weight", (64, 3, kt, 1, 1), "float32"), ("bn.0.weight", (64,), "float32"), ("bn.0.bias", (64,), "float32"),
            ("bn.0.running_mean", (64,), "float32"), ("bn.0.running_var", (64,), "float32")]
     sd = synth.fill_layout(lay, seed)
     sd["conv.weight"] = sd["conv.weight"] * 3.0                     # fan-out init is tiny for a 1x1 spatial kernel
+    sd["bn.0.weight"][1::2] *= -1.0
+    sd["bn.0.weight"][4] = 0.0
     x = synth.synthetic_tensor((n, 3, t, h, w), seed)
+    x[0, 1, t // 2, 3, 5] = float("nan")
     if dtype != "f32":
         x = x.to(hh.TORCH_DT[dtype]).float()
         sd["conv.weight"] = sd["conv.weight"].to(hh.TORCH_DT[dtype]).float()
@@ -132,8 +137,10 @@ def test_temporal_stem_vs_oracle(dtype, dims, kt):
                                              hh._stream()), "tstem")
     got = hh.to_ncdhw(out).double()
     tol = {"f32": 2e-6, "f16": 1.5e-3, "bf16": 1.2e-2}[dtype]
-    err = (got - want).abs().max().item()
-    assert err <= tol * (want.abs().max().item() + 1e-9), err
+    nan = torch.isnan(want)
+    assert nan.any() and not nan.all() and (torch.isnan(got) == nan).all()
+    err = (got - want)[~nan].abs().max().item()
+    assert err <= tol * (want[~nan].abs().max().item() + 1e-9), err
 
 
 def test_ftcn_plugin_surface_batch_and_hook(ftcn_weights, tmp_path):
