@@ -62,15 +62,55 @@ __global__ __launch_bounds__(256) void tstem_kernel(const TStemArgs a) {
     __shared__ uint4 patch_all[DT == AF_F32 ? 1 : 4 * 128];
     char* patch = reinterpret_cast<char*>(patch_all) + (DT == AF_F32 ? 0 : (threadIdx.x >> 6) * 2048);
 
-    for (unsigned tile = (unsigned)wave0; tile < (unsigned)a.tiles; tile += (unsigned)nwaves) {   // (tiles < 2^31: host-checked)
-        const int tw = (int)(tile % (unsigned)a.tiles_w); unsigned q = tile / (unsigned)a.tiles_w;
-        const int ph = (int)(q % (unsigned)a.Ho); q /= (unsigned)a.Ho;
-        const int t = (int)(q % (unsigned)a.T); const long long n = q / (unsigned)a.T;
-        int pw = tw * 16 + frow;                                        // pooled column of this lane
-        const bool live = pw < a.Wo;
-        if (!live) pw = a.Wo - 1;                                       // ragged last tile: clamped, never stored
-        const char* px = a.in + ((n * a.Tp + t + a.t_off) * plane_b) + (long long)(2 * ph + AF_STEM_PAD_H) * row_b +
-                         (long long)(2 * pw + AF_STEM_PAD_W_LEFT) * PIXB;
+    struct Where { int tw, ph, t, pw; long long n; bool live; const char* px; };
+    auto locate = [&](unsigned tile) {                                  // (tiles < 2^31: host-checked)
+        Where w;
+        w.tw = (int)(tile % (unsigned)a.tiles_w); unsigned q = tile / (unsigned)a.tiles_w;
+        w.ph = (int)(q % (unsigned)a.Ho); q /= (unsigned)a.Ho;
+        w.t = (int)(q % (unsigned)a.T); w.n = q / (unsigned)a.T;
+        w.pw = w.tw * 16 + frow;                                        // pooled column of this lane
+        w.live = w.pw < a.Wo;
+        if (!w.live) w.pw = a.Wo - 1;                                   // ragged last tile: clamped, never stored
+        w.px = a.in + ((w.n * a.Tp + w.t + a.t_off) * plane_b) + (long long)(2 * w.ph + AF_STEM_PAD_H) * row_b +
+               (long long)(2 * w.pw + AF_STEM_PAD_W_LEFT) * PIXB;
+        return w;
+    };
+    // 16-bit: the two horizontal window members are adjacent 8-byte pixels - one 16-byte load (8-byte aligned: the left
+    // padding is odd) per (row, tap) serves both: 4 loads of 256 contiguous bytes per lane group instead of 8 strided
+    // 8-byte ones; lane group fg holds taps 2fg, 2fg+1 (taps >= kt have zero weights and are not read).  The loads of the
+    // NEXT tile are issued before this tile's MFMAs and epilogue.
+    typedef u32x4 __attribute__((aligned(8))) u32x4_a8;
+    auto load_taps = [&](const char* px, uint4 (&l)[2][2]) {
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int tp = 0; tp < 2; ++tp) {
+                l[dy][tp] = uint4{0u, 0u, 0u, 0u};
+                if (fg * 2 + tp < a.kt) l[dy][tp] = __builtin_bit_cast(uint4, *reinterpret_cast<const u32x4_a8*>(px + dy * row_b + (fg * 2 + tp) * plane_b));
+            }
+    };
+    unsigned tile = (unsigned)wave0;
+    Where nxt = locate(tile < (unsigned)a.tiles ? tile : 0u);
+    uint4 lnext[2][2];
+    if (DT != AF_F32 && tile < (unsigned)a.tiles) load_taps(nxt.px, lnext);
+    for (; tile < (unsigned)a.tiles; tile += (unsigned)nwaves) {
+        const Where cur = nxt;
+        const int tw = cur.tw, ph = cur.ph, t = cur.t, pw = cur.pw;
+        const long long n = cur.n;
+        const bool live = cur.live;
+        const char* px = cur.px;
+        uint4 l[2][2];
+        if (DT != AF_F32) {
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy) { l[dy][0] = lnext[dy][0]; l[dy][1] = lnext[dy][1]; }
+            if (tile + (unsigned)nwaves < (unsigned)a.tiles) {
+                nxt = locate(tile + (unsigned)nwaves);
+                load_taps(nxt.px, lnext);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        } else if (tile + (unsigned)nwaves < (unsigned)a.tiles) {
+            nxt = locate(tile + (unsigned)nwaves);
+        }
         f32x4 acc[4][4];                                                // [window member][channel tile]
 #pragma unroll
         for (int m = 0; m < 4; ++m)
@@ -90,18 +130,6 @@ __global__ __launch_bounds__(256) void tstem_kernel(const TStemArgs a) {
                     for (int i = 0; i < 4; ++i) Mma<DT>::run(wf[kb][i], b, acc[m][i]);
                 }
             } else {
-                // 16-bit: the two horizontal window members are adjacent 8-byte pixels - one 16-byte load (8-byte aligned:
-                // the left padding is odd) per (row, tap) serves both: 4 loads of 256 contiguous bytes per lane group
-                // instead of 8 strided 8-byte ones
-                typedef u32x4 __attribute__((aligned(8))) u32x4_a8;
-                uint4 l[2][2];
-#pragma unroll
-                for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-                    for (int tp = 0; tp < 2; ++tp) {
-                        l[dy][tp] = uint4{0u, 0u, 0u, 0u};
-                        if (tap0 + tp < a.kt) l[dy][tp] = __builtin_bit_cast(uint4, *reinterpret_cast<const u32x4_a8*>(px + dy * row_b + (tap0 + tp) * plane_b));
-                    }
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
                     const uint4 &l0 = l[m >> 1][0], &l1 = l[m >> 1][1];
