@@ -113,6 +113,76 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const StemArgs a) {
     }
 }
 
+// Narrow stems (<= 16 output channels: SlowFast's 8-channel Fast pathway), 16-bit.  With one channel tile every MFMA
+// needs its own 16-byte activation fragment from L1 and the kernel above is bound by exactly that (one fragment load per
+// MFMA; L1 delivers 64 B/clk per CU).  Output rows ho and ho+1 share 5 of their 7 input rows, so here a wave owns 16
+// columns x R CONSECUTIVE OUTPUT ROWS: per dt plane it loads the 2R+5 input rows once and feeds 7R MFMAs from them
+// (R = 8: 21 loads for 56 MFMAs instead of 56), the 7 weight fragments of the plane coming from an LDS image of all
+// kt slices that is loaded once per workgroup.
+template <int DT, int R>
+__global__ __launch_bounds__(256) void stem_rows_kernel(const StemArgs a, int tiles_w, int hblocks, long long units) {
+    typedef Elem<DT> E;
+    constexpr int EPC = E::EPC, ES = 16 / EPC, NCH = 4, PIXB = 4 * ES, NR = 2 * R + 5;
+    static_assert(EPC == 8, "16-bit types only (one 16-byte chunk per lane and K-row)");
+    extern __shared__ uint4 wlds[];                      // [kt][kh][NCH][16]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int frow = lane & 15, fg = lane >> 4;
+    const int wchunks = a.kt * a.kh * NCH * 16;
+    for (int i = tid; i < wchunks; i += 256) wlds[i] = reinterpret_cast<const uint4*>(a.w)[i];
+    __syncthreads();
+    const long long unit = (long long)blockIdx.x * 4 + wave;
+    if (unit >= units) return;
+    const int wt = (int)(unit % tiles_w); long long q = unit / tiles_w;
+    const int hb = (int)(q % hblocks); q /= hblocks;
+    const int to = (int)(q % a.To); const long long n = q / a.To;
+    const int ho0 = hb * R;
+    int wo = wt * 16 + frow;
+    const bool col_ok = wo < a.Wo;
+    if (!col_ok) wo = a.Wo - 1;                          // clamp: loads stay inside the row, result never stored
+    const long long row_bytes = (long long)a.Wp * PIXB, plane_bytes = row_bytes * a.Hp;
+    const char* base = a.in + ((((n * a.Tp + to) * a.Hp + 2 * ho0) * a.Wp) + 2 * wo) * PIXB + fg * 16;
+    const int rmax = a.Hp - 1 - 2 * ho0;                 // last input row that exists below the block's first one
+
+    f32x4 acc[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int dt = 0; dt < a.kt; ++dt) {
+        uint4 bx[NR], af[7];
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+            bx[r] = *reinterpret_cast<const uint4*>(base + dt * plane_bytes + (long long)(r < rmax ? r : rmax) * row_bytes);
+#pragma unroll
+        for (int dh = 0; dh < 7; ++dh) af[dh] = wlds[((dt * 7 + dh) * NCH + fg) * 16 + frow];
+#pragma unroll
+        for (int j = 0; j < R; ++j)
+#pragma unroll
+            for (int dh = 0; dh < 7; ++dh) Mma<DT>::run(af[dh], bx[2 * j + dh], acc[j]);
+    }
+    const int ch = fg * 4;
+    if (!col_ok || ch >= a.cout) return;
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + ch), sf = *reinterpret_cast<const f32x4*>(a.shift + ch);
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        if (ho0 + j >= a.Ho) break;
+        const long long m = ((n * a.To + to) * a.Ho + ho0 + j) * a.Wo + wo;
+        f32x4 v = acc[j] * sc + sf;
+        v[0] = relu_f(v[0]); v[1] = relu_f(v[1]); v[2] = relu_f(v[2]); v[3] = relu_f(v[3]);
+        Vec4<DT>::store(a.out + (m * a.cout + ch) * ES, v);
+    }
+}
+
+template <int DT>
+static int launch_stem_rows(const StemArgs& a, hipStream_t stream) {
+    constexpr int R = 8;
+    const int tiles_w = (a.Wo + 15) / 16, hblocks = (a.Ho + R - 1) / R;
+    const long long n_to = a.M / ((long long)a.Ho * a.Wo), units = n_to * hblocks * tiles_w, blocks = (units + 3) / 4;
+    if (blocks > 0x7fffffffLL) return set_error(AF_ERR_ARG, "stem: grid too large");
+    const int lds = a.kt * a.kh * 4 * 16 * 16;
+    hipLaunchKernelGGL((stem_rows_kernel<DT, R>), dim3((unsigned)blocks), dim3(256), lds, stream, a, tiles_w, hblocks, units);
+    AF_CHECK_LAUNCH("stem_rows_kernel");
+    return AF_OK;
+}
+
 template <int DT, int TN>
 static int launch_stem_tn(const StemArgs& a, hipStream_t stream) {
     constexpr int NCH = 32 / Elem<DT>::EPC;
@@ -129,6 +199,10 @@ static int launch_stem_tn(const StemArgs& a, hipStream_t stream) {
 
 template <int DT>
 static int launch_stem(const StemArgs& a, hipStream_t stream) {
+    if (a.cout <= 16 && a.kh == 7) {
+        if (DT == AF_BF16) return launch_stem_rows<AF_BF16>(a, stream);
+        if (DT == AF_F16) return launch_stem_rows<AF_F16>(a, stream);
+    }
     return a.cout <= 16 ? launch_stem_tn<DT, 1>(a, stream) : launch_stem_tn<DT, 4>(a, stream);
 }
 

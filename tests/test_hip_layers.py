@@ -119,6 +119,32 @@ def test_stem_unfused_path_and_odd_sizes(golden_f3, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cout,kt,shape", [(8, 5, (2, 6, 50, 70)),      # Fast pathway: conv out 25x35 (ragged 8-row blocks, ragged column tile)
+                                           (8, 5, (1, 3, 32, 32)),      # exactly two row blocks, one column tile
+                                           (16, 1, (1, 2, 18, 40)),     # kt = 1 (Slow-pathway style), 16 channels
+                                           (4, 3, (1, 4, 14, 14))])     # fewer rows than a block
+def test_narrow_stem_vs_oracle(dtype, cout, kt, shape):
+    """[kt,7,7] stride [1,2,2] stems with <= 16 output channels (SlowFast's 8-channel Fast-pathway stem): the 16-bit path is
+    the row-sharing kernel (a wave owns 16 columns x 8 output rows), fp32 the generic stem kernel."""
+    n, t, h, w = shape
+    seed = 900 + cout + kt
+    lay = [("conv.weight", (cout, 3, kt, 7, 7), "float32"), ("bn.weight", (cout,), "float32"), ("bn.bias", (cout,), "float32"),
+           ("bn.running_mean", (cout,), "float32"), ("bn.running_var", (cout,), "float32")]
+    sd = synth.fill_layout(lay, seed)
+    x = synth.synthetic_tensor((n, 3, t, h, w), seed)
+    if dtype != "f32":
+        x = x.to(hh.TORCH_DT[dtype]).float()
+        sd["conv.weight"] = sd["conv.weight"].to(hh.TORCH_DT[dtype]).float()
+    want = oracle.conv_bn_act(x.double(), sd["conv.weight"].double(), {k: v.double() for k, v in sd.items()}, "bn", (1, 2, 2),
+                              (kt // 2, 3, 3), True)
+    sin = hh.pack_input_f32(x.cuda(), dtype)
+    got = hh.to_ncdhw(hh.stem_conv(sin, (n, t, h, w), sd["conv.weight"], *hh.fold_bn(sd, "bn"), dtype)).double()
+    assert got.shape == want.shape
+    tol = {"f32": 5e-6, "f16": 1.5e-3, "bf16": 1.2e-2}[dtype]
+    assert (got - want).abs().max().item() <= tol * (want.abs().max().item() + 1e-9)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_projection_block_unfused_path(golden_f3, dtype):
     """the same blocks with the shortcut as its own launch + residual add (generic path of af_conv3d_bn_act)"""
     cases, arrays = golden_f3
