@@ -362,6 +362,31 @@ def test_conv_out_ld_writes_into_concat_buffer():
     assert (wide[..., 128:].cpu() - want).abs().max().item() <= 1e-5
 
 
+def test_stream_kernel_out_ld_and_temporal_pool_into_concat_buffer():
+    """the persistent 1x1x1 stream (plain and with the fused frame-pair max) writing at a channel offset of a wider tensor:
+    only its 256 columns change, row pitch = out_ld."""
+    dtype = "bf16"
+    lay = [("w.weight", (256, 64, 1, 1, 1), "float32"), ("bn.weight", (256,), "float32"), ("bn.bias", (256,), "float32"),
+           ("bn.running_mean", (256,), "float32"), ("bn.running_var", (256,), "float32")]
+    sd = synth.fill_layout(lay, 15)
+    sd["w.weight"] = sd["w.weight"].to(torch.bfloat16).float()
+    dims = (2, 8, 96, 96)
+    x = synth.synthetic_tensor((dims[0], 64) + dims[1:], 16).to(torch.bfloat16).float()
+    y = oracle.conv_bn_act(x.double(), sd["w.weight"].double(), {k: v.double() for k, v in sd.items()}, "bn", (1, 1, 1), (0, 0, 0), True)
+    for tpool in (False, True):
+        t_out = dims[1] // 2 if tpool else dims[1]
+        want = (F.max_pool3d(y, (2, 1, 1), (2, 1, 1)) if tpool else y).permute(0, 2, 3, 4, 1)
+        wide = torch.full((dims[0], t_out, 96, 96, 320), 7.0, dtype=torch.bfloat16, device="cuda")
+        view = wide.view(-1, 320)[:, 32:288]
+        assert view.data_ptr() % 16 == 0
+        hh.conv_bn_act(hh.to_ndhwc(x, dtype), sd["w.weight"], *hh.fold_bn(sd, "bn"), (1, 1, 1), (0, 0, 0), True, dtype,
+                       out=view, out_ld=320, tpool=tpool)
+        assert hh.conv_bn_act.last_variant == 10
+        assert torch.all(wide[..., :32] == 7.0) and torch.all(wide[..., 288:] == 7.0)
+        got = wide[..., 32:288].float().cpu().double()
+        assert (got - want).abs().max().item() <= 1.2e-2 * want.abs().max().item()
+
+
 def test_input_prologue_u8_matches_callers():
     u8 = synth.synthetic_clips_u8(2, seed=3, kind="uniform", num_frames=3, size=10)
     x = synth.normalize_like_callers(u8)                       # (B,3,T,H,W) view, channels-last strides
