@@ -204,13 +204,15 @@ CONV_CASES = [
     ("stream111_64to256_ragged", 64, 256, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 9, 121, 121), True, False),
     ("stream111_128to512_res_ragged", 128, 512, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 6, 107, 109), False, True),
     ("stream111_256to1024_res_ragged", 256, 1024, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 4, 91, 93), True, True),   # 32-channel wave columns
+    ("stream111_64to768_three_columns", 64, 768, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 5, 95, 97), True, True),    # grid not a multiple of 8 x columns
 ]
 EXPECT_VARIANT = {"tile256_1x3x3_res": 6, "tile256_ragged_m": 6, "tile512_1x3x3_res": 7, "tile512_ragged_m": 7,
                   "t311_64to64_T32": 8, "t311_256to64_T16": 8, "t311_256to64_T32_many": 8,
                   "t311_256to128_T16": {"f32": 3, "f16": 8, "bf16": 8},
                   "stream111_64to256_res": {"f32": 2, "f16": 10, "bf16": 10}, "stream111_64to256_ragged": {"f32": 2, "f16": 10, "bf16": 10},
                   "stream111_128to512_res_ragged": {"f32": 5, "f16": 10, "bf16": 10},
-                  "stream111_256to1024_res_ragged": {"f32": 5, "f16": 10, "bf16": 10}}
+                  "stream111_256to1024_res_ragged": {"f32": 5, "f16": 10, "bf16": 10},
+                  "stream111_64to768_three_columns": {"f32": 2, "f16": 10, "bf16": 10}}
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
