@@ -14,8 +14,10 @@
  *     accumulation is always fp32; BatchNorm is applied as a per-channel fp32 scale/shift
  *     in the producing kernel's epilogue;
  *   - kernels are enqueued asynchronously on `stream` (a hipStream_t passed as void*,
- *     NULL = the null stream); nothing here synchronises, allocates or frees device memory,
- *     except the *_timed entry points which record and wait for their own events;
+ *     NULL = the null stream); nothing here synchronises, allocates or frees device memory (scratch a launch
+ *     may need is sized by af_conv_workspace_bytes() and passed in by the caller), except the *_timed entry
+ *     points which record and wait for their own events; there is no mutable global state beyond per-device
+ *     "attribute already set" flags, so launches on different streams / devices of one process do not interact;
  *   - return value 0 = success, negative = error; af_last_error() (thread-local text).
  */
 #ifndef AF_HIP_H
@@ -27,7 +29,7 @@
 extern "C" {
 #endif
 
-#define AF_ABI_VERSION 1
+#define AF_ABI_VERSION 2
 
 enum af_dtype { AF_F32 = 0, AF_BF16 = 1, AF_F16 = 2 };
 
@@ -134,10 +136,17 @@ int af_stem_conv_bn_relu_maxpool(const af_conv_desc* d, const void* stem_in, con
  * Requires cin % 8 == 0 and cout % 8 == 0 (fp32: % 4); scale/shift have af_padded_channels(cout) entries.
  * `residual` (NULL or [n][to][ho][wo][cout]) is added before the ReLU.
  * `out_ld` = channel stride of `out` rows in elements (>= cout; lets FuseFastToSlow write into
- * the concatenated slow tensor), 0 means cout. */
+ * the concatenated slow tensor), 0 means cout.
+ * `workspace` / `workspace_bytes`: caller-owned device scratch (16-byte aligned) for the split-K path that small
+ * batches take in long-K layers (a live call's 1-3 clips: a layer with a handful of tiles splits its K range over up
+ * to 8 workgroups per tile, fp32 partial sums meet in the workspace).  af_conv_workspace_bytes(d) is the size this
+ * layer can use (0: never splits); with NULL or fewer bytes the layer runs unsplit (same result to fp32 rounding).  The
+ * workspace is free for reuse as soon as the NEXT launch on the same stream has been enqueued; launches that may run
+ * concurrently (different streams) need one each. */
+int64_t af_conv_workspace_bytes(const af_conv_desc* d);
 int af_conv3d_bn_act(const af_conv_desc* d, const void* in, const void* w_packed,
                      const float* scale, const float* shift, const void* residual,
-                     void* out, int out_ld, void* stream);
+                     void* out, int out_ld, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* Block 0 of a stage as ONE launch: relu( bn_c(conv_c(b)) + bn_1(conv_1(x)) ), i.e. the last 1x1x1 of the
  * bottleneck plus the projection shortcut `branch1` (1x1x1, stride [1,s,s]) of ResBlock
@@ -269,6 +278,9 @@ typedef struct af_op {
     /* PACK_* only */
     int64_t in_strides[5];           /* n,c,t,h,w element strides of the fp32 source */
     float mean[3], std_[3];
+    /* CONV only: split-K scratch (af_conv3d_bn_act) */
+    void* workspace;
+    int64_t workspace_bytes;
 } af_op;
 
 /* Enqueue ops[0..n) in order on `stream` (AltFreezing: ResNet.forward, video_model_builder.py:561-578). */

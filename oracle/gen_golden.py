@@ -13,6 +13,7 @@ is committed; no reference source travels.
 Fixtures
   layout.json       the reference's ``network.state_dict()`` keys / shapes / dtypes
   f1_logits.json    full-size logits, fp32 and fp64, W(seed=0), three seeded clips
+  f1b_logits.json   B=16 logits of BASELINE config[1]'s batch (W(0)) + 8 clips on the "hot" checkpoint W(3, hot), fp32/fp64
   f2_stages.npz     per-stage statistics + sampled activations for clip 0
   f3_kats.npz/.json per-layer-class known-answer tests on small tensors
   f4_load.json      behaviour table of ``ModelBase.load`` on crafted checkpoints
@@ -122,6 +123,46 @@ def gen_f1_f2(clf):
                    "weights_sha256": synth.state_dict_sha256(sd), "clips": entries,
                    "batch2_uniform_logits_f32": batch2}, f, indent=1)
     np.savez_compressed(os.path.join(GOLD, "f2_stages.npz"), **f2)
+
+
+def gen_f1b(clf):
+    """F1b: (a) BASELINE config[1]'s own batch - W(0), B=16 uniform clips seed 2026 (exactly bench.py's rank-0 input) in ONE
+    reference forward; (b) the "hot" checkpoint W(3, hot) whose logits are O(10..40) and move between clips, 8 clips
+    (4 uniform + 4 smooth), fp32 and fp64.  Written by the reference's own forward, as F1."""
+    out = {"source": "reference i3d_ori forward, PyTorch CPU, weights loaded via ModelBase.load", "torch": torch.__version__}
+
+    def load(sd):
+        with tempfile.TemporaryDirectory() as td:
+            path = os.path.join(td, "w.pth")
+            torch.save({"state_dict": sd}, path)
+            ok, epoch = clf.load(path)
+            assert ok and epoch == -1
+
+    sd0 = synth.synthetic_state_dict(seed=WEIGHT_SEED)
+    load(sd0)
+    u8 = synth.synthetic_clips_u8(16, seed=CLIP_SEED, kind="uniform")
+    with torch.no_grad():
+        y = clf(synth.normalize_like_callers(u8))["final_output"]
+    out["batch16"] = {"weights_seed": WEIGHT_SEED, "recipe": "mild", "weights_sha256": synth.state_dict_sha256(sd0),
+                      "kind": "uniform", "seed": CLIP_SEED, "clips_sha256": synth.tensor_sha256(u8),
+                      "logits_f32": [float(v) for v in y.flatten()]}
+    print("F1b batch16", out["batch16"]["logits_f32"])
+    sd3 = synth.synthetic_state_dict(seed=3, recipe="hot")
+    load(sd3)
+    u8 = torch.cat([synth.synthetic_clips_u8(4, seed=11, kind="uniform"), synth.synthetic_clips_u8(4, seed=12, kind="smooth")])
+    x = synth.normalize_like_callers(u8)
+    with torch.no_grad():
+        y32 = clf(x)["final_output"]
+        clf64 = clf.double()
+        y64 = torch.cat([clf64(x[i:i + 1].double())["final_output"] for i in range(x.shape[0])])
+        clf.float()
+    out["hot"] = {"weights_seed": 3, "recipe": "hot", "weights_sha256": synth.state_dict_sha256(sd3),
+                  "clips": [["uniform", 11, 4], ["smooth", 12, 4]], "clips_sha256": synth.tensor_sha256(u8),
+                  "logits_f32": [float(v) for v in y32.flatten()], "logits_f64": [float(v) for v in y64.flatten()]}
+    print("F1b hot f32", out["hot"]["logits_f32"])
+    print("F1b hot f64", out["hot"]["logits_f64"])
+    with open(os.path.join(GOLD, "f1b_logits.json"), "w") as f:
+        json.dump(out, f, indent=1)
 
 
 def _fill(module, seed, prefix, final_bn=(), linear=()):
@@ -518,6 +559,7 @@ def main():
     gen_f3()
     gen_f4(clf)
     gen_f1_f2(clf)
+    gen_f1b(clf)
     gen_slowfast()
     gen_dualrun()
     gen_aligner()
@@ -531,6 +573,11 @@ if __name__ == "__main__":
         os.makedirs(GOLD, exist_ok=True)
         torch.set_num_threads(8)
         gen_dualrun()
+    elif "--f1b" in sys.argv:
+        os.makedirs(GOLD, exist_ok=True)
+        torch.manual_seed(0)
+        torch.set_num_threads(8)
+        gen_f1b(ref_import.build_reference_classifier())
     elif "--ftcn" in sys.argv:
         os.makedirs(GOLD, exist_ok=True)
         torch.manual_seed(0)

@@ -9,7 +9,7 @@ LIB_PATH = os.environ.get("AF_HIP_LIB") or os.path.join(HERE, "libafhip.so")   #
 AF_F32, AF_BF16, AF_F16 = 0, 1, 2
 (AF_OP_STEM, AF_OP_CONV, AF_OP_MAXPOOL, AF_OP_HEAD, AF_OP_PACK_F32, AF_OP_PACK_U8, AF_OP_CONV_DUAL, AF_OP_STEM_POOL, AF_OP_AVGPOOL,
  AF_OP_LINEAR, AF_OP_TSTEM, AF_OP_TOKENS, AF_OP_LAYERNORM, AF_OP_ATTENTION, AF_OP_GELU) = range(15)
-AF_ABI_VERSION = 1
+AF_ABI_VERSION = 2
 STEM_PAD_T, STEM_PAD_H, STEM_PAD_W_LEFT, STEM_PAD_W_TOTAL, STEM_CPAD = 2, 3, 3, 8, 4
 
 DTYPE_CODES = {"f32": AF_F32, "bf16": AF_BF16, "f16": AF_F16}
@@ -44,10 +44,12 @@ class Op(C.Structure):
         ("conv2", ConvDesc), ("in2", C.c_void_p), ("weight2", C.c_void_p),
         ("in_strides", C.c_int64 * 5),
         ("mean", C.c_float * 3), ("std_", C.c_float * 3),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
     ]
 
 
-# name -> (restype, argtypes); this table is also what tests/test_abi.py checks against include/af_hip.h
+# name -> (restype, argtypes); tests/test_host_cpu.py::test_c_abi_exports_every_declared_symbol checks this table against
+# include/af_hip.h and the built library
 ABI = {
     "af_version": (C.c_int, []),
     "af_last_error": (C.c_char_p, []),
@@ -65,7 +67,8 @@ ABI = {
                                                                   C.c_int, C.c_void_p, C.c_void_p]),
     "af_stem_conv_bn_relu": (C.c_int, [C.POINTER(ConvDesc)] + [C.c_void_p] * 6),
     "af_stem_conv_bn_relu_maxpool": (C.c_int, [C.POINTER(ConvDesc)] + [C.c_void_p] * 6),
-    "af_conv3d_bn_act": (C.c_int, [C.POINTER(ConvDesc)] + [C.c_void_p] * 6 + [C.c_int, C.c_void_p]),
+    "af_conv_workspace_bytes": (C.c_int64, [C.POINTER(ConvDesc)]),
+    "af_conv3d_bn_act": (C.c_int, [C.POINTER(ConvDesc)] + [C.c_void_p] * 6 + [C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
     "af_conv3d_dual_bn_act": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_void_p, C.POINTER(ConvDesc)] + [C.c_void_p] * 5
                               + [C.c_int, C.c_void_p]),
     "af_conv_variant": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvDesc)]),

@@ -1,8 +1,8 @@
 """Declarative description of the AltFreezing ``i3d_ori`` network (I3D-ResNet-50).
 
 This is the single source of truth that both the host-side module skeleton
-(``classifier.py``) and the HIP execution plan (``plan.py`` -> csrc/af_plan.hip)
-are generated from.  It restates *what* the reference builds, not how:
+(``classifier.py``) and the HIP execution plan (``engine.py``: the flat ``af_op`` list run by
+``af_run_ops``, csrc/af_api.hip) are generated from.  It restates *what* the reference builds, not how:
 
 * plugin yaml ``MODEL.ARCH: i3d``, ``RESNET.DEPTH: 50``  (reference
   altfreezing/model/classifier/i3d_ori.py:4-62)

@@ -93,7 +93,11 @@ class _HipNetwork(nn.Module):
         self._build_head()
         _init_like_reference(self)
         self._packed: Dict[str, Tuple[tuple, object]] = {}      # dtype -> (signature, PackedWeights)
-        self._engines: Dict[tuple, object] = {}                 # (dtype, batch, dims) -> Engine
+        # (dtype, batch, dims) -> Engine, least recently used first.  An engine owns a full activation set (about 3 GB
+        # at B=16 in bf16), so a live-call service whose face count changes per step must not pin one per batch size
+        # forever: at most ``max_engines`` stay alive (288 GB of HBM make 8 a comfortable default).
+        self._engines: "OrderedDict[tuple, object]" = OrderedDict()
+        self.max_engines = 8
 
     def _build_head(self):
         _attach(self, "resnet.head.dropout", nn.Dropout(0.5))
@@ -103,6 +107,13 @@ class _HipNetwork(nn.Module):
         return self.resnet.head.projection
 
     # -- weight / engine caches ---------------------------------------------------------------------
+    def invalidate_packed(self):
+        """Drops the packed device weights and every engine; the next forward repacks from the current parameters.
+        Needed after edits the signature cannot see: in-place writes through ``.data`` (``p.data.copy_(...)``) do
+        not bump a tensor's version counter.  ``load()`` / ``load_state_dict()`` / ``.to()`` are detected."""
+        self._packed.clear()
+        self._engines.clear()
+
     def _signature(self):
         first = next(self.parameters())
         ver = 0
@@ -124,9 +135,14 @@ class _HipNetwork(nn.Module):
         if cached is None or cached[0] != sig:
             state = {k: v for k, v in self.state_dict().items()}
             self._packed[dtype] = (sig, PackedWeights(self.spec, state, dtype, device))
-            self._engines = {k: e for k, e in self._engines.items() if k[0] != dtype}
+            for k in [k for k in self._engines if k[0] == dtype]:
+                del self._engines[k]
         key = (dtype, batch, tuple(dims))
-        if key not in self._engines:
+        if key in self._engines:
+            self._engines.move_to_end(key)
+        else:
+            while len(self._engines) >= max(1, self.max_engines):
+                self._engines.popitem(last=False)            # least recently used; its buffers go back to the allocator
             self._engines[key] = Engine(self.spec, self._packed[dtype][1], batch, device, dims)
         return self._engines[key]
 

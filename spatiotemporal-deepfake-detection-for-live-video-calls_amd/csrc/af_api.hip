@@ -15,6 +15,17 @@ int set_error(int code, const char* fmt, ...) {
     return code;
 }
 
+int device_cus() {
+    static int cus[kMaxDevices] = {};
+    const int dev = current_device();
+    if (dev >= 0 && cus[dev] > 0) return cus[dev];
+    int n = 0, d = dev < 0 ? 0 : dev;
+    if (dev < 0) (void)hipGetDevice(&d);
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || n <= 0) n = 256;   // MI355X
+    if (dev >= 0) cus[dev] = n;
+    return n;
+}
+
 static int run_one(const af_op& op, hipStream_t s) {
     switch (op.kind) {
         case AF_OP_STEM:
@@ -22,7 +33,8 @@ static int run_one(const af_op& op, hipStream_t s) {
         case AF_OP_STEM_POOL:
             return af_stem_conv_bn_relu_maxpool(&op.conv, op.in, op.weight, op.scale, op.shift, op.out, s);
         case AF_OP_CONV:
-            return af_conv3d_bn_act(&op.conv, op.in, op.weight, op.scale, op.shift, op.residual, op.out, op.out_ld, s);
+            return af_conv3d_bn_act(&op.conv, op.in, op.weight, op.scale, op.shift, op.residual, op.out, op.out_ld, op.workspace,
+                                    op.workspace_bytes, s);
         case AF_OP_CONV_DUAL:
             return af_conv3d_dual_bn_act(&op.conv, op.in, op.weight, &op.conv2, op.in2, op.weight2, op.scale, op.shift,
                                          op.out, op.out_ld, s);

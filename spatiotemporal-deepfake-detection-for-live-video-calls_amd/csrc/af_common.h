@@ -62,6 +62,31 @@ int conv111_run(const af_conv_desc* d, const void* in, const void* w_packed, con
                 const void* w2_packed, const float* scale, const float* shift, const void* residual, void* out, int out_ld,
                 hipStream_t stream);
 
+// One-time PER-DEVICE setup.  hipFuncSetAttribute and the CU count belong to a device, and one process may drive several
+// (one engine per device): every "done once" flag is therefore indexed by the current device ordinal.
+constexpr int kMaxDevices = 64;
+static inline int current_device() {
+    int d = 0;
+    return (hipGetDevice(&d) == hipSuccess && d >= 0 && d < kMaxDevices) ? d : -1;
+}
+struct DeviceOnce { bool done[kMaxDevices] = {}; };
+// compute units of the current device (cached per device; af_api.hip)
+int device_cus();
+
+// raise a kernel's dynamic-LDS limit once per (kernel instantiation, device)
+#define AF_SET_MAX_LDS(kernel_ptr, bytes, what)                                                                        \
+    do {                                                                                                               \
+        static af::DeviceOnce once__;                                                                                  \
+        const int dev__ = af::current_device();                                                                        \
+        if (dev__ < 0 || !once__.done[dev__]) {                                                                        \
+            hipError_t e__ = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel_ptr),                            \
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (bytes));                 \
+            if (e__ != hipSuccess)                                                                                     \
+                return af::set_error(AF_ERR_LAUNCH, "%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e__));      \
+            if (dev__ >= 0) once__.done[dev__] = true;                                                                 \
+        }                                                                                                              \
+    } while (0)
+
 #define AF_REQUIRE(cond, ...)                                    \
     do {                                                         \
         if (!(cond)) return af::set_error(AF_ERR_ARG, __VA_ARGS__); \

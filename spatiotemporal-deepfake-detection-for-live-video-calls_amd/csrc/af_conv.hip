@@ -52,6 +52,7 @@ struct ConvArgs {
     // [y * S / ksplit, (y + 1) * S / ksplit) and leaves raw fp32 partial sums in ws[y][M][Cout]; splitk_finish_kernel adds them
     int ksplit;
     float* ws;
+    long long ws_bytes;  // caller's workspace (ws == nullptr or too small: no split)
 };
 
 // NW = WN*WM*KS = 8 waves (512 threads); wave (wn, wm) owns a (BN/WN) x (BM/WM) sub-tile of 16x16
@@ -518,14 +519,8 @@ static int launch(const ConvArgs& a, hipStream_t stream) {
     const int slots = (MINW >= 4 && a.ring == 2) ? 2 : NSTAGE;
     const int ring_bytes = (S < slots ? S : slots) * (BN + BM) * 128;
     const int lds = ring_bytes > patch_bytes ? ring_bytes : patch_bytes;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<DT, BN, BM, WN, WM, KS, NSTAGE, MINW, DUAL, SPLITK>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           NSTAGE * (BN + BM) * 128 > patch_bytes ? NSTAGE * (BN + BM) * 128 : patch_bytes);
-        if (e != hipSuccess) return set_error(AF_ERR_LAUNCH, "conv: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_set = true;
-    }
+    AF_SET_MAX_LDS((&conv_igemm_kernel<DT, BN, BM, WN, WM, KS, NSTAGE, MINW, DUAL, SPLITK>),
+                   NSTAGE * (BN + BM) * 128 > patch_bytes ? NSTAGE * (BN + BM) * 128 : patch_bytes, "conv");
     hipLaunchKernelGGL((conv_igemm_kernel<DT, BN, BM, WN, WM, KS, NSTAGE, MINW, DUAL, SPLITK>), dim3((unsigned)blocks, SPLITK ? a.ksplit : 1), dim3(WN * WM * KS * 64), lds, stream, a);
     AF_CHECK_LAUNCH("conv_igemm_kernel");
     return AF_OK;
@@ -586,19 +581,20 @@ __global__ void splitk_finish_kernel(const float* ws, int ksplit, long long M, i
     Vec4<DT>::store(out + (m * out_ld + c) * ES, v);
 }
 
-// the partial-sum workspace: one per process, grown on demand (a handful of MB; only small-batch launches split K).
-// Not re-entrant across streams: two forwards running concurrently on different streams of one process must not both
-// take the split-K path (the engine enqueues a forward on one stream).
-static float* g_splitk_ws = nullptr;
-static size_t g_splitk_bytes = 0;
-static float* splitk_workspace(size_t bytes) {
-    if (bytes > g_splitk_bytes) {
-        if (g_splitk_ws) { (void)hipDeviceSynchronize(); (void)hipFree(g_splitk_ws); g_splitk_ws = nullptr; g_splitk_bytes = 0; }
-        const size_t want = bytes + bytes / 2;
-        if (hipMalloc(reinterpret_cast<void**>(&g_splitk_ws), want) != hipSuccess) { g_splitk_ws = nullptr; return nullptr; }
-        g_splitk_bytes = want;
-    }
-    return g_splitk_ws;
+// M-rows of a variant's tile
+static int variant_bm(int v) { return v == VAR_128x512 ? 512 : (v == VAR_128x256 || v == VAR_64x256 || v == VAR_256x256) ? 256 : 128; }
+static int variant_bn(int v) {
+    return v == VAR_256x256 ? 256 : (v == VAR_128x256 || v == VAR_128x512 || v == VAR_128x128 || v == VAR_128x128_R2) ? 128 : 64;
+}
+// split K when the tiles alone leave most CUs idle (one clip, the deep stages): up to 8 K ranges of >= 8 K-steps each whose
+// fp32 partial sums meet in the CALLER's workspace (ksplit * M * Cout floats); 1 = no split
+static int plan_ksplit(int v, long long M, int coutp, int cout, int s_all, int tpool, bool dual) {
+    const long long blocks = (M + variant_bm(v) - 1) / variant_bm(v) * (coutp / variant_bn(v));
+    if (tpool || dual || blocks >= 128 || s_all < 16 || cout % 4 != 0) return 1;
+    int ks = (int)(256 / blocks);
+    if (ks > 8) ks = 8;
+    if (ks > s_all / 8) ks = s_all / 8;
+    return ks >= 2 ? ks : 1;
 }
 
 template <int DT>
@@ -610,25 +606,11 @@ static int dispatch(ConvArgs& a, hipStream_t stream) {
     a.Cin2P = a.kpt2 * BK;
     a.CoutP = (a.Cout + 63) / 64 * 64;
     const int v = pick_variant(a.CoutP, a.CinP, a.kt * a.kh * a.kw, DT, a.M, a.in2 ? a.Cin2P : 0, a.tpool);
-    a.tiles_n = a.CoutP / (v == VAR_256x256 ? 256 : (v == VAR_128x256 || v == VAR_128x512 || v == VAR_128x128 || v == VAR_128x128_R2) ? 128 : 64);
+    a.tiles_n = a.CoutP / variant_bn(v);
     a.ring = v == VAR_128x128_R2 ? 2 : 3;
-    // split K when the tiles alone leave most CUs idle (one clip, the deep stages): up to 8 K ranges, >= 8 K-steps each
-    a.ksplit = 1; a.ws = nullptr;
-    {
-        const int bm = (v == VAR_128x512) ? 512 : (v == VAR_128x256 || v == VAR_64x256 || v == VAR_256x256) ? 256 : 128;
-        const long long blocks = (a.M + bm - 1) / bm * a.tiles_n;
-        const int S_all = a.kt * a.kh * a.kw * a.kpt + a.kpt2;
-        if (!a.tpool && !a.in2 && blocks < 128 && S_all >= 16 && a.Cout % 4 == 0) {
-            int ks = (int)(256 / blocks);
-            if (ks > 8) ks = 8;
-            if (ks > S_all / 8) ks = S_all / 8;
-            if (ks >= 2) {
-                a.ws = splitk_workspace((size_t)ks * (size_t)a.M * a.Cout * sizeof(float));
-                if (!a.ws) return set_error(AF_ERR_LAUNCH, "conv: cannot allocate the %d-way split-K workspace", ks);
-                a.ksplit = ks;
-            }
-        }
-    }
+    // split K (small batches) only into a workspace the caller handed over and that is large enough
+    a.ksplit = plan_ksplit(v, a.M, a.CoutP, a.Cout, a.kt * a.kh * a.kw * a.kpt + a.kpt2, a.tpool, a.in2 != nullptr);
+    if (a.ksplit > 1 && (!a.ws || a.ws_bytes < (long long)a.ksplit * a.M * a.Cout * (long long)sizeof(float))) a.ksplit = 1;
     int rc;
     if (a.in2) {                                 // projection blocks (64-wide tiles: SlowFast's Fast pathway)
         switch (v) {
@@ -685,9 +667,20 @@ extern "C" const char* af_conv_variant_name(int variant) {
     return (variant >= 0 && variant < af::VAR_COUNT) ? af::kVariantNames[variant] : "?";
 }
 
+extern "C" int64_t af_conv_workspace_bytes(const af_conv_desc* d) {
+    using namespace af;
+    if (!d || d->cout <= 0 || d->cin <= 0 || !dtype_ok(d->dtype) || d->n <= 0 || d->to <= 0 || d->ho <= 0 || d->wo <= 0) return 0;
+    const int bk = d->dtype == AF_F32 ? 32 : 64;
+    const int coutp = (d->cout + 63) / 64 * 64, cinp = (d->cin + bk - 1) / bk * bk, taps = d->kt * d->kh * d->kw;
+    const long long M = (long long)d->n * d->to * d->ho * d->wo;
+    const int v = pick_variant(coutp, cinp, taps, d->dtype, M, 0, d->tpool);
+    const int ks = plan_ksplit(v, M, coutp, d->cout, taps * (cinp / bk), d->tpool, false);
+    return ks > 1 ? (int64_t)ks * M * d->cout * (int64_t)sizeof(float) : 0;
+}
+
 static int conv_common(const af_conv_desc* d, const void* in, const void* w_packed, const af_conv_desc* d2,
                        const void* in2, const void* w2_packed, const float* scale, const float* shift,
-                       const void* residual, void* out, int out_ld, void* stream) {
+                       const void* residual, void* out, int out_ld, void* workspace, int64_t workspace_bytes, void* stream) {
     using namespace af;
     AF_REQUIRE(d && in && w_packed && scale && shift && out, "conv: null argument");
     AF_REQUIRE(dtype_ok(d->dtype), "conv: bad dtype %d", d->dtype);
@@ -727,6 +720,8 @@ static int conv_common(const af_conv_desc* d, const void* in, const void* w_pack
     a.kt = d->kt; a.kh = d->kh; a.kw = d->kw; a.st = d->st; a.sh = d->sh; a.sw = d->sw;
     a.pt = d->pt; a.ph = d->ph; a.pw = d->pw; a.To = to; a.Ho = ho; a.Wo = wo;
     a.relu = d->relu; a.out_ld = out_ld;
+    AF_REQUIRE(aligned16(workspace) && workspace_bytes >= 0, "conv: the workspace must be 16-byte aligned");
+    a.ws = (float*)workspace; a.ws_bytes = workspace ? workspace_bytes : 0;
     AF_REQUIRE(d->tpool >= 0 && d->tpool <= 2, "conv: tpool must be 0, 1 (temporal pairs) or 2 (2x2 pixels)");
     a.tpool = d->tpool;
     AF_REQUIRE(a.tpool != 1 || (to % 2 == 0), "conv: fused temporal pool needs an even number of output frames (%d)", to);
@@ -760,13 +755,14 @@ static int conv_common(const af_conv_desc* d, const void* in, const void* w_pack
 }
 
 extern "C" int af_conv3d_bn_act(const af_conv_desc* d, const void* in, const void* w_packed, const float* scale,
-                                const float* shift, const void* residual, void* out, int out_ld, void* stream) {
-    return conv_common(d, in, w_packed, nullptr, nullptr, nullptr, scale, shift, residual, out, out_ld, stream);
+                                const float* shift, const void* residual, void* out, int out_ld, void* workspace,
+                                int64_t workspace_bytes, void* stream) {
+    return conv_common(d, in, w_packed, nullptr, nullptr, nullptr, scale, shift, residual, out, out_ld, workspace, workspace_bytes, stream);
 }
 
 extern "C" int af_conv3d_dual_bn_act(const af_conv_desc* d, const void* in, const void* w_packed,
                                      const af_conv_desc* d2, const void* in2, const void* w2_packed, const float* scale,
                                      const float* shift, void* out, int out_ld, void* stream) {
     AF_REQUIRE(d2, "conv_dual: null second descriptor");
-    return conv_common(d, in, w_packed, d2, in2, w2_packed, scale, shift, nullptr, out, out_ld, stream);
+    return conv_common(d, in, w_packed, d2, in2, w2_packed, scale, shift, nullptr, out, out_ld, nullptr, 0, stream);
 }

@@ -267,27 +267,10 @@ __global__ __launch_bounds__(512, 1) void conv111_kernel(const C111Args a) {
 template <int DT, int KS1, int KS2, bool TPOOL, bool RES, int WC = 64>
 static int launch111(const C111Args& a, int blocks, hipStream_t stream) {
     const int lds = 2 * (KS1 + KS2) * 128 * 128 + 8 * 16 * (WC + 4) * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv111_kernel<DT, KS1, KS2, TPOOL, RES, WC>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return set_error(AF_ERR_LAUNCH, "conv111: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_set = true;
-    }
+    AF_SET_MAX_LDS((&conv111_kernel<DT, KS1, KS2, TPOOL, RES, WC>), lds, "conv111");
     hipLaunchKernelGGL((conv111_kernel<DT, KS1, KS2, TPOOL, RES, WC>), dim3(blocks), dim3(512), lds, stream, a);
     AF_CHECK_LAUNCH("conv111_kernel");
     return AF_OK;
-}
-
-static int device_cus() {
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
-            n = 256;
-        cus = n;
-    }
-    return cus;
 }
 
 // position tiles of the layer if it takes this path, 0 otherwise

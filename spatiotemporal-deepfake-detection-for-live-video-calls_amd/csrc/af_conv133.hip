@@ -195,31 +195,17 @@ __global__ __launch_bounds__(256, 1) void conv133_c64_kernel(const C133Args a) {
     }
 }
 
-static int g_num_cus = 0;
-
 template <int DT>
 static int launch_c133(C133Args& a, hipStream_t stream) {
     constexpr int R = 4;
-    if (g_num_cus == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
-            return set_error(AF_ERR_LAUNCH, "conv133: cannot query the device");
-        g_num_cus = prop.multiProcessorCount;
-    }
+    const int g_num_cus = device_cus();
     const int WP = a.W + 2;
     a.strips_per_frame = (a.H + R - 1) / R;
     a.total_strips = a.frames * a.strips_per_frame;
     a.rows_alloc = (((R + 2) * WP + 2 + 16) + 7) & ~7;
     const int lds = 2 * a.rows_alloc * 128 + 16 * 16 * 128 + 128 * 4 + (a.rows_alloc / 8) * 64 * 4;
     const int grid = a.total_strips < g_num_cus ? a.total_strips : g_num_cus;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv133_c64_kernel<DT, R>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return set_error(AF_ERR_LAUNCH, "conv133: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_set = true;
-    }
+    AF_SET_MAX_LDS((&conv133_c64_kernel<DT, R>), 160 * 1024, "conv133");
     hipLaunchKernelGGL((conv133_c64_kernel<DT, R>), dim3(grid), dim3(256), lds, stream, a);
     AF_CHECK_LAUNCH("conv133_c64_kernel");
     return AF_OK;

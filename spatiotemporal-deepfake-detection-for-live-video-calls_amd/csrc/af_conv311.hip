@@ -167,13 +167,7 @@ template <int DT, int BN>
 static int launch311(const C311Args& a, int blocks, hipStream_t stream) {
     constexpr int BM = 256 / (BN / 64), EPC = Elem<DT>::EPC;
     const int lds = 2 * (3 * BN + BM + 2 * a.P) * 128 + 8 * 16 * (64 + EPC) * (16 / EPC);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv311_kernel<DT, BN>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return set_error(AF_ERR_LAUNCH, "conv311: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_set = true;
-    }
+    AF_SET_MAX_LDS((&conv311_kernel<DT, BN>), 160 * 1024, "conv311");
     hipLaunchKernelGGL((conv311_kernel<DT, BN>), dim3(blocks), dim3(512), lds, stream, a);
     AF_CHECK_LAUNCH("conv311_kernel");
     return AF_OK;
@@ -208,13 +202,7 @@ int conv311_run(const af_conv_desc* d, const void* in, const void* w_packed, con
     a.T = d->t; a.HW = d->h * d->w; a.Cin = d->cin; a.kpt = d->cin / (d->dtype == AF_F32 ? 32 : 64);
     a.P = conv311_tile_rows(d) / d->t; a.chunks = (a.HW + a.P - 1) / a.P; a.tiles = d->n * a.chunks;
     a.relu = d->relu; a.out_ld = out_ld;
-    static int cus = 0;                                  // persistent grid: one workgroup per CU
-    if (cus == 0) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
-            n = 256;
-        cus = n;
-    }
+    const int cus = device_cus();                        // persistent grid: one workgroup per CU
     const int blocks = a.tiles < cus ? a.tiles : cus;
     if (d->cout == 128) return d->dtype == AF_BF16 ? launch311<AF_BF16, 128>(a, blocks, stream) : launch311<AF_F16, 128>(a, blocks, stream);
     switch (d->dtype) {

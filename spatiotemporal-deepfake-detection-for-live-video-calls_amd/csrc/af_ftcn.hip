@@ -351,13 +351,7 @@ extern "C" int af_attention(const float* qkv, int clips, int n_tok, int heads, i
                "attention: at most %d tokens x %d per head (got %d x %d)", ATT_MAX_TOK, ATT_MAX_DH, n_tok, dim_head);
     if (clips == 0) return AF_OK;
     const int lds = (3 * n_tok * dim_head + n_tok * n_tok) * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (3 * ATT_MAX_TOK * ATT_MAX_DH + ATT_MAX_TOK * ATT_MAX_TOK) * 4);
-        if (e != hipSuccess) return set_error(AF_ERR_LAUNCH, "attention: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_set = true;
-    }
+    AF_SET_MAX_LDS(&attention_kernel, (3 * ATT_MAX_TOK * ATT_MAX_DH + ATT_MAX_TOK * ATT_MAX_TOK) * 4, "attention");
     hipLaunchKernelGGL(attention_kernel, dim3(clips * heads), dim3(128), lds, (hipStream_t)stream, qkv, n_tok, heads, dim_head,
                        1.0f / sqrtf((float)dim_head), out);
     AF_CHECK_LAUNCH("attention_kernel");

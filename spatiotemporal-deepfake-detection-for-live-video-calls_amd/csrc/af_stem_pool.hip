@@ -175,26 +175,12 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const StemPoolArgs a)
     }
 }
 
-static int g_cus = 0;
-
 template <int DT, int KT>
 static int launch_stem_pool_kt(const StemPoolArgs& a, hipStream_t stream) {
-    if (g_cus == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
-            return set_error(AF_ERR_LAUNCH, "stem_pool: cannot query the device");
-        g_cus = prop.multiProcessorCount;
-    }
+    const int g_cus = device_cus();
     const int lds = a.kt * 7 * 4 * 64 * 16 + ((a.Wo + 15) / 16) * 16 * 64 * 2;
     if (lds > 160 * 1024) return set_error(AF_ERR_ARG, "stem_pool: %d bytes of LDS needed", lds);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_pool_kernel<DT, KT>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return set_error(AF_ERR_LAUNCH, "stem_pool: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_set = true;
-    }
+    AF_SET_MAX_LDS((&stem_pool_kernel<DT, KT>), 160 * 1024, "stem_pool");
     const int units = a.frames * a.bands;
     const int grid = units < g_cus ? units : g_cus;           // one resident workgroup per CU; weights loaded once each
     hipLaunchKernelGGL((stem_pool_kernel<DT, KT>), dim3(grid), dim3(512), lds, stream, a);
@@ -237,9 +223,7 @@ extern "C" int af_stem_conv_bn_relu_maxpool(const af_conv_desc* d, const void* s
     // fewer frames than CUs (batch < 8 clips of 32 frames): cut every frame into bands of pooled rows so that the whole
     // chip works; a band costs one extra (unstored) row pair, so no bands once the frames alone fill the CUs
     {
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-            cus = 256;
+        const int cus = device_cus();
         int bands = a.frames >= cus ? 1 : cus / a.frames;
         if (bands > a.Hq / 4) bands = a.Hq / 4 > 0 ? a.Hq / 4 : 1;      // at least 4 pooled rows per band
         a.band_rows = (a.Hq + bands - 1) / bands;

@@ -452,6 +452,18 @@ class Engine:
                 self.op_macs.append(0)
             else:
                 raise KeyError(kind)
+        # split-K scratch (small batches, long-K layers): sized by the library, owned by this engine (one per engine =
+        # one per device and per stream of work, since an engine enqueues its forward on one stream); consecutive
+        # launches of one forward reuse it in stream order
+        need = 0
+        for i in range(self.n_ops):
+            if self.ops[i].kind == _lib.AF_OP_CONV:
+                need = max(need, int(lib.af_conv_workspace_bytes(C.byref(self.ops[i].conv))))
+        self.workspace = torch.empty(need // 4, dtype=torch.float32, device=device) if need else None
+        for i in range(self.n_ops):
+            if self.ops[i].kind == _lib.AF_OP_CONV and need:
+                self.ops[i].workspace = self.workspace.data_ptr()
+                self.ops[i].workspace_bytes = need
 
     TT_HEAD_OPS = 12
 

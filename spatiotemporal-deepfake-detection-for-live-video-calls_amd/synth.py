@@ -26,9 +26,15 @@ def _gen(seed: int, idx: int) -> torch.Generator:
     return g
 
 
-def fill_layout(layout, seed: int, final_bn=(), linear=()) -> "OrderedDict[str, torch.Tensor]":
+def fill_layout(layout, seed: int, final_bn=(), linear=(), recipe: str = "mild") -> "OrderedDict[str, torch.Tensor]":
     """Applies the W(seed) recipe to any [(key, shape, dtype_name)] layout.
-    ``final_bn``: BN prefixes that get the small-gamma rule; ``linear``: nn.Linear prefixes."""
+    ``final_bn``: BN prefixes that get the small-gamma rule; ``linear``: nn.Linear prefixes.
+    ``recipe``: "mild" (every block's last BN gamma ~ U(0, 0.4), head N(0, 0.05): logits O(0.3), nearly input
+    independent) or "hot" (last BN gamma ~ U(0.3, 0.9), head N(0, 0.1): the residual branches dominate, logits are
+    O(10..40) and move by O(1..10) between clips - a localized kernel bug shows in the logit)."""
+    if recipe not in ("mild", "hot"):
+        raise ValueError(recipe)
+    hot = recipe == "hot"
     final_bn, linear = set(final_bn), set(linear)
     sd = OrderedDict()
     for idx, (key, shape, dtype) in enumerate(layout):
@@ -42,12 +48,12 @@ def fill_layout(layout, seed: int, final_bn=(), linear=()) -> "OrderedDict[str, 
             t = torch.randn(shape, generator=g) * math.sqrt(2.0 / fan_out)
         elif prefix in linear:
             # transformer-head linears: the reference's own trunc_normal std (time_transformer.py:262-266)
-            t = torch.randn(shape, generator=g) * (0.02 if ".transformer." in key else 0.05)
+            t = torch.randn(shape, generator=g) * (0.02 if ".transformer." in key else 0.1 if hot else 0.05)
         elif leaf in ("pos_embedding", "cls_token"):           # transformer head parameters: randn like the reference
             t = torch.randn(shape, generator=g)
         elif leaf == "weight":                                 # BN gamma
             if prefix in final_bn:
-                t = torch.rand(shape, generator=g) * 0.4
+                t = torch.rand(shape, generator=g) * 0.6 + 0.3 if hot else torch.rand(shape, generator=g) * 0.4
             else:
                 t = torch.rand(shape, generator=g) + 0.5
         elif leaf == "bias":
@@ -62,12 +68,12 @@ def fill_layout(layout, seed: int, final_bn=(), linear=()) -> "OrderedDict[str, 
     return sd
 
 
-def synthetic_state_dict(spec: NetSpec = None, seed: int = 0) -> "OrderedDict[str, torch.Tensor]":
+def synthetic_state_dict(spec: NetSpec = None, seed: int = 0, recipe: str = "mild") -> "OrderedDict[str, torch.Tensor]":
     """W(seed): fp32 CPU tensors keyed/ordered like the reference state_dict."""
     spec = spec or i3d_r50_spec()
     linear = spec.linear_prefixes() if hasattr(spec, "linear_prefixes") else [spec.head]
     return fill_layout(state_dict_layout(spec), seed,
-                       final_bn=[cv.bn_key for cv in spec.convs() if cv.final_bn], linear=linear)
+                       final_bn=[cv.bn_key for cv in spec.convs() if cv.final_bn], linear=linear, recipe=recipe)
 
 
 def synthetic_tensor(shape, seed: int, scale: float = 1.0) -> torch.Tensor:

@@ -41,7 +41,10 @@ def fold_bn(sd, prefix):
     return scale, shift
 
 
-def conv_bn_act(x_ndhwc, w_oidhw, scale, shift, stride, pad, relu, dtype, residual=None, out=None, out_ld=0, tpool=False):
+def conv_bn_act(x_ndhwc, w_oidhw, scale, shift, stride, pad, relu, dtype, residual=None, out=None, out_ld=0, tpool=False,
+                workspace="auto"):
+    """workspace: "auto" = a caller-owned scratch of af_conv_workspace_bytes(d) bytes (the split-K path of small layers),
+    None = no workspace (the layer must then run unsplit)."""
     L = lib()
     code = L.DTYPE_CODES[dtype]
     n, t, h, w, cin = x_ndhwc.shape
@@ -62,8 +65,12 @@ def conv_bn_act(x_ndhwc, w_oidhw, scale, shift, stride, pad, relu, dtype, residu
     if out is None:
         q = 2 if int(tpool) == 2 else 1
         out = torch.empty((n, d.to // 2 if int(tpool) == 1 else d.to, d.ho // q, d.wo // q, cout), dtype=TORCH_DT[dtype], device="cuda")
+    ws_bytes = L.lib.af_conv_workspace_bytes(C.byref(d)) if workspace == "auto" else 0
+    ws = torch.empty(max(ws_bytes // 4, 4), dtype=torch.float32, device="cuda") if ws_bytes else None
+    conv_bn_act.last_workspace_bytes = ws_bytes
     L.check(L.lib.af_conv3d_bn_act(C.byref(d), _p(x_ndhwc), _p(packed), _p(scale), _p(shift), _p(residual), _p(out),
-                                   out_ld, _stream()), "conv3d_bn_act")
+                                   out_ld, _p(ws), ws_bytes, _stream()), "conv3d_bn_act")
+    torch.cuda.current_stream().synchronize()          # ws / packed stay referenced until the launch has run
     return out
 
 

@@ -1,10 +1,14 @@
 """GPU: the whole HIP forward behind the drop-in Classifier against the golden logits / stage
 activations produced by the imported reference (tests/golden/f1_logits.json, f2_stages.npz).
 
-Stated tolerances on the O(0.3) logits of the synthetic checkpoint W(0):
-  f32  : 1e-3 required by BASELINE.json's north_star; asserted at 2e-4 (exact-fp32 MFMA path)
-  f16  : 1e-2  (the reference's own GPU deployment precision, torch.amp.autocast fp16)
-  bf16 : 6e-2  (BASELINE config[1]; the reference under CPU bf16 autocast is itself 4.4e-3..1e-2 off)
+Stated tolerances on the O(0.3) logits of the synthetic checkpoint W(0) (north_star: "logits within 1e-3 of the CPU
+reference"):
+  f32  : asserted at 2e-4 (exact-fp32 MFMA path; measures 1.5e-6)
+  f16  : asserted at 1e-3 - the north-star tolerance (measures 2.5e-4..3.2e-4); the reference's own GPU deployment
+         precision (torch.amp.autocast fp16, test/af_realtime.py:70,84)
+  bf16 : BF16_TOL below - the measured bound with a little margin.  bf16 (8 significant bits) does NOT reliably meet
+         1e-3: the reference itself under CPU bf16 autocast is 4.4e-3..1e-2 off.  Documented, not hidden.
+On the "hot" checkpoint (|logit| 18..33, tests/golden/f1b_logits.json) the 16-bit bounds are relative to |logit|.
 """
 import os
 import sys
@@ -14,7 +18,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import ROOT, load_npz
+from conftest import ROOT, load_json, load_npz
 
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import i3d_oracle as oracle  # noqa: E402
@@ -22,7 +26,9 @@ from af_mi355x import synth  # noqa: E402
 from af_mi355x.classifier import Classifier  # noqa: E402
 
 pytestmark = pytest.mark.gpu
-LOGIT_TOL = {"f32": 2e-4, "f16": 1e-2, "bf16": 6e-2}
+BF16_TOL = 1e-2
+LOGIT_TOL = {"f32": 2e-4, "f16": 1e-3, "bf16": BF16_TOL}
+REL_TOL = {"f32": 1e-5, "f16": 1.5e-3, "bf16": 1.2e-2}       # hot checkpoint: |d| <= REL_TOL * |logit|
 
 
 @pytest.fixture(scope="module")
@@ -207,7 +213,7 @@ def test_small_network_vs_oracle_all_dtypes():
     u8 = synth.synthetic_clips_u8(3, seed=9, kind="smooth", num_frames=clip_size, size=size)
     x = synth.normalize_like_callers(u8)
     want = oracle.forward(sd, x, num_frames=clip_size, crop=size)
-    for dtype, tol in (("f32", 1e-4), ("f16", 1e-2), ("bf16", 6e-2)):
+    for dtype, tol in (("f32", 1e-4), ("f16", 1e-3), ("bf16", 1e-2)):
         clf = Classifier(clip_size=clip_size, precision=dtype, crop_size=size)
         clf.network.load_state_dict(sd)
         clf = clf.to("cuda").eval()
@@ -230,7 +236,7 @@ def test_non_finite_pixel_gives_nan_logit_like_reference():
     x[1, 2, 3, 17, 40] = float("nan")
     want = oracle.forward(sd, x, num_frames=clip_size, crop=size)
     assert torch.isnan(want[1]).all() and torch.isfinite(want[[0, 2]]).all()
-    for dtype, tol in (("f32", 1e-4), ("f16", 1e-2), ("bf16", 6e-2)):
+    for dtype, tol in (("f32", 1e-4), ("f16", 1e-3), ("bf16", 1e-2)):
         clf = Classifier(clip_size=clip_size, precision=dtype, crop_size=size)
         clf.network.load_state_dict(sd)
         clf = clf.to("cuda").eval()
@@ -238,3 +244,90 @@ def test_non_finite_pixel_gives_nan_logit_like_reference():
             got = clf(x.cuda())["final_output"].cpu()
         assert torch.isnan(got[1]).all(), (dtype, got)
         assert (got[[0, 2]] - want[[0, 2]]).abs().max().item() <= tol, (dtype, got, want)
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16", "f32"])
+def test_config1_batch16_at_its_own_dtype(weights0, dtype):
+    """BASELINE config[1] as benchmarked: B=16 uniform clips (seed 2026 = bench.py's rank-0 batch), one forward, against the
+    reference's own B=16 forward (tests/golden/f1b_logits.json).  The engine picks its kernels by batch (stream kernels need
+    >= 4 tiles per CU, split-K below 128 workgroups, the 256x256 tile rules), so this is the plan the bench times."""
+    g = load_json("f1b_logits.json")["batch16"]
+    assert synth.state_dict_sha256(weights0) == g["weights_sha256"]
+    u8 = synth.synthetic_clips_u8(16, seed=g["seed"], kind=g["kind"])
+    assert synth.tensor_sha256(u8) == g["clips_sha256"]
+    clf = Classifier(precision=dtype)
+    clf.network.load_state_dict(weights0)
+    clf = clf.cuda().eval()
+    with torch.inference_mode():
+        y = clf.network.forward_clips_u8(u8.cuda())["final_output"].cpu().flatten()
+        y2 = clf(synth.normalize_like_callers(u8.cuda()))["final_output"].cpu().flatten()
+    want = torch.tensor(g["logits_f32"])
+    err = (y - want).abs().max().item()
+    print("B=16 %s: max|d| %.3e (tolerance %.1e)" % (dtype, err, LOGIT_TOL[dtype]))
+    assert torch.equal(y, y2)                              # uint8 prologue == callers' fp32 normalisation
+    assert (dtype, 16, (32, 224, 224)) in clf.network._engines
+    assert err <= LOGIT_TOL[dtype], (dtype, err)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16", "bf16"])
+def test_hot_checkpoint_logits(dtype):
+    """Second weight seed with |logit| 18..33 that moves between clips (F1b "hot"): 8 clips in one batch."""
+    g = load_json("f1b_logits.json")["hot"]
+    sd = synth.synthetic_state_dict(seed=g["weights_seed"], recipe=g["recipe"])
+    assert synth.state_dict_sha256(sd) == g["weights_sha256"]
+    u8 = torch.cat([synth.synthetic_clips_u8(n, seed=seed, kind=kind) for kind, seed, n in g["clips"]])
+    assert synth.tensor_sha256(u8) == g["clips_sha256"]
+    clf = Classifier(precision=dtype)
+    clf.network.load_state_dict(sd)
+    clf = clf.cuda().eval()
+    with torch.inference_mode():
+        y = clf.network.forward_clips_u8(u8.cuda())["final_output"].cpu().flatten().double()
+    want32, want64 = torch.tensor(g["logits_f32"]).double(), torch.tensor(g["logits_f64"]).double()
+    rel = ((y - want32).abs() / want32.abs()).max().item()
+    print("hot %s: max rel %.3e, abs %.3e; fp32-vs-fp64 of the reference itself %.3e"
+          % (dtype, rel, (y - want32).abs().max().item(), (want32 - want64).abs().max().item()))
+    assert rel <= REL_TOL[dtype], (dtype, rel)
+    if dtype == "f32":                                     # the 1e-3 north-star tolerance holds in absolute terms too
+        assert (y - want32).abs().max().item() <= 1e-3
+
+
+def test_split_k_workspace_is_caller_owned_and_stream_ordered(weights0):
+    """The B=1..3 live-call path splits K in the deep stages into a workspace the ENGINE owns (af_conv_workspace_bytes):
+    a B=1 engine then a B=3 engine run back to back on one stream with no synchronisation in between - the library
+    neither allocates nor synchronises - and both match the oracle.  A second stream gets engines of its own."""
+    u8 = synth.synthetic_clips_u8(3, seed=31, kind="smooth")
+    x = synth.normalize_like_callers(u8)
+    want = oracle.forward(weights0, x).flatten()
+    clf = Classifier(precision="f32")
+    clf.network.load_state_dict(weights0)
+    clf = clf.cuda().eval()
+    xd = x.cuda()
+    with torch.inference_mode():
+        clf(xd[:1]); clf(xd)                                  # build both engines (weights packed, buffers allocated)
+        torch.cuda.synchronize()
+        e1 = clf.network._engines[("f32", 1, (32, 224, 224))]
+        e3 = clf.network._engines[("f32", 3, (32, 224, 224))]
+        assert e1.workspace is not None and e3.workspace is not None, "one clip in s5 must take the split-K path"
+        assert e1.workspace.data_ptr() != e3.workspace.data_ptr()
+        ya = clf(xd[:1])["final_output"]                      # no sync between the two forwards
+        yb = clf(xd)["final_output"]
+        yc = clf(xd[2:3])["final_output"]
+        torch.cuda.synchronize()
+    got = torch.cat([ya.flatten(), yb.flatten(), yc.flatten()]).cpu()
+    exp = torch.cat([want[:1], want, want[2:3]])
+    assert (got - exp).abs().max().item() <= LOGIT_TOL["f32"], (got, exp)
+
+
+def test_engine_cache_is_bounded(weights0):
+    clf = Classifier(clip_size=8, precision="f16", crop_size=64)
+    from af_mi355x.arch import i3d_r50_spec
+    clf.network.load_state_dict(synth.synthetic_state_dict(i3d_r50_spec(8, 64), seed=5))
+    clf = clf.cuda().eval()
+    clf.network.max_engines = 3
+    with torch.inference_mode():
+        ys = {b: clf(torch.zeros((b, 3, 8, 64, 64), device="cuda"))["final_output"].cpu() for b in (1, 2, 3, 4, 5, 1)}
+    assert len(clf.network._engines) == 3
+    assert list(clf.network._engines)[-1][1] == 1            # most recently used last
+    assert torch.allclose(ys[1][0], ys[5][0], atol=2e-3)
+    clf.network.invalidate_packed()
+    assert not clf.network._engines and not clf.network._packed

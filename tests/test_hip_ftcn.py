@@ -1,7 +1,7 @@
 """GPU: the reference's second plugin, FTCN-TT, on the HIP kernels against the golden
 logits / stage samples / head known-answer produced by the reference plugin itself (tests/golden/f6_ftcn*), plus
 the plugin-specific kernels against the CPU oracle on small cases.
-Tolerances: f32 2e-4 (north star 1e-3), f16 1e-2, bf16 6e-2 on an O(1) logit - as for the other networks."""
+Tolerances: f32 2e-4 (north star 1e-3), f16 1e-3 (= the north star), bf16 1e-2 (measured bound + margin; bf16 does not reliably meet 1e-3) on an O(1) logit - as for the other networks."""
 import ctypes as C
 import os
 import sys
@@ -34,7 +34,7 @@ def _clip(c):
     return synth.normalize_like_callers(u8).cuda()
 
 
-@pytest.mark.parametrize("dtype,tol", [("f32", 2e-4), ("f16", 1e-2), ("bf16", 6e-2)])
+@pytest.mark.parametrize("dtype,tol", [("f32", 2e-4), ("f16", 1e-3), ("bf16", 1e-2)])
 def test_ftcn_logits_match_reference(ftcn_weights, dtype, tol):
     g, sd = ftcn_weights
     net = FtcnTT8x8(precision=dtype)
@@ -156,7 +156,7 @@ def test_ftcn_plugin_surface_batch_and_hook(ftcn_weights, tmp_path):
         yb = clf(x)["final_output"]
         y0 = clf(x[:1])["final_output"]
     assert yb.shape == (2, 1) and torch.allclose(yb[:1], y0, rtol=0, atol=2e-3)     # f16; batch sizes may split K differently
-    assert abs(float(yb[1, 0]) - g["clips"][1]["logit_f32"]) <= 1e-2
+    assert abs(float(yb[1, 0]) - g["clips"][1]["logit_f32"]) <= 1e-3
     last = [m for m in clf.network.modules() if isinstance(m, torch.nn.Linear)][-1]
     seen = {}
     hdl = last.register_forward_hook(lambda m, i, o: seen.update(i=i[0].detach(), o=o.detach()))

@@ -1,6 +1,6 @@
 """GPU: the two-pathway SlowFast-R50 on the HIP kernels against the golden
 logits and stage samples produced by the reference's own ``SlowFast`` module (tests/golden/f5_slowfast*).
-Tolerances as for the single-pathway net: f32 2e-4 (north star 1e-3), f16 1e-2, bf16 6e-2."""
+Tolerances as for the single-pathway net: f32 2e-4 (north star 1e-3), f16 1e-3 (= the north star), bf16 1e-2 (measured bound + margin; bf16 does not reliably meet 1e-3)."""
 import numpy as np
 import pytest
 import torch
@@ -26,7 +26,7 @@ def _clip(c):
     return synth.normalize_like_callers(u8).cuda()
 
 
-@pytest.mark.parametrize("dtype,tol", [("f32", 2e-4), ("f16", 1e-2), ("bf16", 6e-2)])
+@pytest.mark.parametrize("dtype,tol", [("f32", 2e-4), ("f16", 1e-3), ("bf16", 1e-2)])
 def test_slowfast_logits_match_reference(sf_weights, dtype, tol):
     g, sd = sf_weights
     net = SlowFast8x8(precision=dtype)

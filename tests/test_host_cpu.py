@@ -164,7 +164,7 @@ def test_c_abi_exports_every_declared_symbol():
     assert declared == set(_lib.ABI), declared ^ set(_lib.ABI)
     for name in declared:
         assert hasattr(_lib.lib, name)
-    assert _lib.lib.af_version() == 1
+    assert _lib.lib.af_version() == _lib.AF_ABI_VERSION == int(re.search(r"#define AF_ABI_VERSION (\d+)", hdr).group(1))
     import ctypes as C
     assert C.sizeof(_lib.ConvDesc) == 21 * 4 and C.sizeof(_lib.PoolDesc) == 19 * 4
 
@@ -173,8 +173,9 @@ def test_abi_rejects_bad_arguments_without_a_gpu():
     from af_mi355x import _lib
     import ctypes as C
     d = _lib.ConvDesc()
-    assert _lib.lib.af_conv3d_bn_act(C.byref(d), None, None, None, None, None, None, 0, None) == -1
+    assert _lib.lib.af_conv3d_bn_act(C.byref(d), None, None, None, None, None, None, 0, None, 0, None) == -1
     assert b"null" in _lib.lib.af_last_error()
+    assert _lib.lib.af_conv_workspace_bytes(C.byref(d)) == 0 and _lib.lib.af_conv_workspace_bytes(None) == 0
     assert _lib.lib.af_packed_conv_weight_bytes(64, 64, 1, 3, 3, 1) == 64 * 64 * 9 * 2
     assert _lib.lib.af_stem_input_bytes(1, 32, 224, 224, 0) == 36 * 230 * 232 * 4 * 4
 

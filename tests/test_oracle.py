@@ -219,3 +219,21 @@ def test_aligner_warp_restatement_properties():
     m = np.array([[0.83, -0.21, 5.3], [0.21, 0.83, -2.7]])
     out = ao.warp_affine_u8(np.full((30, 30, 3), 200, dtype=np.uint8), m, 48)
     assert out.max() == 200 and set(np.unique(out)) - {0, 200} != set()                # edges blend towards the border 0
+
+
+def test_hot_checkpoint_logits_match_reference():
+    """F1b: the "hot" checkpoint W(3, hot) - logits O(10..40) that move between clips - on one uniform and one smooth clip."""
+    f1b = load_json("f1b_logits.json")["hot"]
+    sd = synth.synthetic_state_dict(seed=f1b["weights_seed"], recipe=f1b["recipe"])
+    assert synth.state_dict_sha256(sd) == f1b["weights_sha256"]
+    u8 = hot_clips(f1b)
+    assert synth.tensor_sha256(u8) == f1b["clips_sha256"]
+    pick = [0, 5]
+    with torch.no_grad():
+        y = oracle.forward(sd, oracle.normalize(u8[pick])).flatten()
+    want = torch.tensor([f1b["logits_f32"][i] for i in pick])
+    assert (y - want).abs().max().item() <= 2e-5 * 40, (y, want)
+
+
+def hot_clips(f1b):
+    return torch.cat([synth.synthetic_clips_u8(n, seed=seed, kind=kind) for kind, seed, n in f1b["clips"]])

@@ -53,6 +53,7 @@ def main():
             n, fs, tf = fetch[k]
             ws = write.get(k, [n, 0.0, 0.0])[1]
             out[k] = {"launches_profiled": n,
+                      "fetch_size_raw_bytes_per_launch": fs * 1024 / n,        # as counted, before the gfx950 2x correction
                       "hbm_read_bytes_per_launch": 2 * fs * 1024 / n,
                       "hbm_write_bytes_per_launch": ws * 1024 / n,
                       "hbm_bytes_per_launch": (2 * fs + ws) * 1024 / n,
