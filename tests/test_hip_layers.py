@@ -406,7 +406,7 @@ def test_argument_errors_are_reported():
     import ctypes as C
     L = hh.lib()
     d = L.ConvDesc()
-    rc = L.lib.af_conv3d_bn_act(C.byref(d), None, None, None, None, None, None, 0, None)
+    rc = L.lib.af_conv3d_bn_act(C.byref(d), None, None, None, None, None, None, 0, None, 0, None)
     assert rc == -1 and b"null" in L.lib.af_last_error()
     x = torch.zeros((1, 1, 4, 4, 42), device="cuda")
     with pytest.raises(L.AfError, match="multiple of"):
