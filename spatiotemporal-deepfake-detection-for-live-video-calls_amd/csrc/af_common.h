@@ -45,6 +45,10 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 bool conv133_applies(const af_conv_desc* d, const void* residual, int out_ld);
 int conv133_run(const af_conv_desc* d, const void* in, const void* w_packed, const float* scale, const float* shift,
                 void* out, hipStream_t stream);
+// af_conv133g.hip: frame / band resident 1x3x3 kernel for 128 / 256 output channels (s3 / s4 `b` convs), 16-bit dtypes
+bool conv133g_applies(const af_conv_desc* d, const void* residual, int out_ld);
+int conv133g_run(const af_conv_desc* d, const void* in, const void* w_packed, const float* scale, const float* shift,
+                 void* out, int out_ld, hipStream_t stream);
 // af_conv_small.hip: direct-gather MFMA path for narrow layers (<= 16 output channels, <= 32 K chunks): SlowFast's Fast pathway
 bool conv_small_applies(const af_conv_desc* d, const af_conv_desc* d2, const void* residual, int out_ld);
 int conv_small_run(const af_conv_desc* d, const void* in, const void* w_packed, const af_conv_desc* d2, const void* in2,

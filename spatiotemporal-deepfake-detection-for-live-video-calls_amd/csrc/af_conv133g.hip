@@ -1,0 +1,266 @@
+// 1x3x3 / stride 1 / pad (0,1,1) convolution, 128 -> 128 or 256 -> 256 channels (any Cin % 64 == 0), 16-bit operands,
+// + BN + ReLU: the `b` convs of the s3 / s4 bottlenecks (reference altfreezing/slowfast/models/resnet_helper.py:283-297).
+//
+// The generic implicit GEMM brings every activation row into LDS once PER TAP (9x) and cuts M into 256 / 512-row tiles:
+// 196 / 392 tiles for the 256 frames of a 16-clip batch, i.e. 77 % of the CUs in the last round.  Here the work unit is
+// a FRAME (s4: 14 x 14) or a band of rows of one (s3: 14 of 28 rows) and all output channels of it:
+//   * per 64-channel K slab the unit's input patch ((R + 2) rows, zero halo included) enters LDS ONCE (LDS-DMA, buffer
+//     loads: out-of-image lanes = out-of-range offsets = zeros) and all 9 taps read it; with the rows kept at a padded
+//     pitch WP = W + 2 a tap (dh, dw) is the constant row shift dh * WP + dw (as in conv133_c64), so every B fragment
+//     is a swizzled ds_read_b128 at an immediate offset; patches are double-buffered, the next slab's pieces trickle
+//     in one per K-step;
+//   * only the weights stream per K-step (tap, slab): a [Cout x 64] tile through a 2-slot LDS-DMA ring - half the
+//     L2 -> LDS ingest per MAC of the generic 256 x 256 tile;
+//   * output positions are the padded band (R x WP; the two halo columns per row are computed and dropped: 12.5 % at
+//     W = 14, 6.7 % at W = 28), 8 waves = WN channel groups of 64 x WM position groups of 7 m-tiles (28 accumulator
+//     tiles per wave); the K loop is software-pipelined by k-halves like the generic kernel's 2-slot variant;
+//   * at B = 16 the 256 frames of s4 are exactly one unit per CU, the 512 half-frames of s3 exactly two rounds.
+#include "af_common.h"
+
+namespace af {
+
+struct C133GArgs {
+    const char* in;
+    const char* w;       // packed [Cout][9][Cin]
+    const float* scale;
+    const float* shift;
+    char* out;
+    int H, W, Cin, Cout, frames;
+    int R, upf;          // output rows per unit, units per frame
+    int WP;              // padded pitch W + 2
+    int prows;           // LDS rows per patch buffer (multiple of 8)
+    int kslabs;          // Cin / 64
+    int relu, out_ld;
+    float inv_wp;
+};
+
+template <int DT, int WN, int WM>
+__global__ __launch_bounds__(512, 2) void conv133g_kernel(const C133GArgs a) {
+    typedef Elem<DT> E;
+    typedef typename E::type OT;
+    static_assert(E::EPC == 8 && WN * WM == 8, "16-bit operands, 8 waves");
+    constexpr int NT = 4, MT = 7;                      // 16x16 tiles per wave: 64 channels x 112 positions
+    constexpr int BN = WN * 64;                        // output channels of the workgroup (= Cout)
+    constexpr int RW = BN / 64;                        // weight DMA pieces per wave per stage
+    constexpr int WSTAGE = BN * 128;                   // bytes of a weight stage ([BN][64 k])
+    constexpr int MAXP = 8;                            // patch DMA pieces per wave (patch <= 512 rows)
+    constexpr int PROW = 64 + 8;                       // epilogue patch row stride (elements)
+
+    extern __shared__ uint4 smem[];
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave % WN, wm = wave / WN;
+    const int frow = lane & 15, fg = lane >> 4;
+    const int WP = a.WP;
+    const int pbytes = a.prows * 128;
+    const unsigned ring0 = lds0 + 2 * pbytes;
+
+    // ---- work unit: (frame, band of R output rows)
+    const int unit = blockIdx.x;
+    const int frame = unit / a.upf, h0 = (unit - frame * a.upf) * a.R;
+
+    // ---- producers.  Weights: thread (lrow = tid >> 3, slot = tid & 7) fetches chunk slot ^ (lrow & 7) of weight rows
+    // lrow + 64 i; the K-step's (tap, slab) offset goes in an SGPR.
+    const int lrow = tid >> 3, wchunk = (tid & 7) ^ (lrow & 7);
+    const long long Kw = 9LL * a.Cin;                                  // weight row length (elements)
+    const i32x4 wdesc = make_desc(a.w);
+    unsigned woff[RW];
+#pragma unroll
+    for (int i = 0; i < RW; ++i) woff[i] = (unsigned)(((lrow + 64 * i) * Kw + wchunk * 8) * 2);
+    // Patch: LDS row j <-> padded pixel q = j - 1 = (r, c) = (q / WP, q % WP) <-> input pixel (h0 - 1 + r, c - 1); rows
+    // beyond the band, halo columns and rows outside the image are out-of-range lanes (zeros).  Piece g = rows 8g .. 8g+7.
+    const int NP = a.prows >> 3;
+    const int drow = lane >> 3, pchunk = (lane & 7) ^ drow;
+    const i32x4 xdesc = make_desc(a.in + (((long long)frame * a.H + h0 - 1) * a.W) * a.Cin * 2);
+    unsigned poff[MAXP];
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i) {
+        const int q = (wave + 8 * i) * 8 + drow - 1;
+        const int r = (int)(((float)q + 0.5f) * a.inv_wp), c = q - r * WP;
+        const bool ok = q >= 0 && r < a.R + 2 && c >= 1 && c <= a.W && (unsigned)(h0 - 1 + r) < (unsigned)a.H;
+        poff[i] = ok ? (unsigned)(((r * a.W + (c - 1)) * a.Cin) * 2 + pchunk * 16) : kOutOfRange;
+    }
+    auto issue_patch_piece = [&](int buf, int slab, int i) {
+        if (wave + 8 * i < NP)
+            blds16(poff[i], xdesc, slab * 128, __builtin_amdgcn_readfirstlane(lds0 + buf * pbytes + (wave + 8 * i) * 1024));
+    };
+    // weight stage for K-step (tap, slab) into ring slot st, one piece (64 rows) at a time
+    auto issue_w_piece = [&](int st, int tap, int slab, int i) {
+        blds16(woff[i], wdesc, (tap * a.Cin + slab * 64) * 2,
+               __builtin_amdgcn_readfirstlane(ring0 + st * WSTAGE + (64 * i + 8 * wave) * 128));
+    };
+
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int S = 9 * a.kslabs;
+    // ---- prologue: patches of slab 0 (and 1), weight stages 0 and 1
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i) issue_patch_piece(0, 0, i);
+#pragma unroll
+    for (int i = 0; i < RW; ++i) issue_w_piece(0, 0, 0, i);
+#pragma unroll
+    for (int i = 0; i < RW; ++i) issue_w_piece(1, 1, 0, i);
+    if (a.kslabs > 1) {
+#pragma unroll
+        for (int i = 0; i < MAXP; ++i) issue_patch_piece(1, 1, i);
+    }
+
+    const char* sm = reinterpret_cast<const char*>(smem);
+    const int arow = (wn * 64 + frow) * 128, brow = (wm * MT * 16 + frow) * 128;
+    // fragments of k-half kk of K-step (tap shift `sh`, patch buffer `buf`, ring slot `st`)
+    uint4 a0[NT], b0[MT], a1[NT], b1[MT];
+    auto read_half = [&](uint4 (&af)[NT], uint4 (&bf)[MT], int st, int buf, int sh, int kk) {
+        const char* wsb = sm + 2 * pbytes + st * WSTAGE + arow + ((((kk << 2) + fg) ^ (frow & 7)) << 4);
+        const char* xsb = sm + buf * pbytes + brow + sh * 128 + ((((kk << 2) + fg) ^ ((frow + sh) & 7)) << 4);
+#pragma unroll
+        for (int i = 0; i < NT; ++i) af[i] = *reinterpret_cast<const uint4*>(wsb + i * (16 * 128));
+#pragma unroll
+        for (int j = 0; j < MT; ++j) bf[j] = *reinterpret_cast<const uint4*>(xsb + j * (16 * 128));
+    };
+    constexpr int NTH = NT * MT;
+
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    // consumer cursor: K-step s = (slab, tap); dh / dw of the tap; the step after it
+    int tap = 0, slab = 0, dh = 0, dw = 0;
+    read_half(a0, b0, 0, 0, 0, 0);
+    for (int s = 0; s + 1 < S; ++s) {
+        const int st = s & 1, buf = slab & 1, sh = dh * WP + dw;
+        // next K-step
+        int ntap = tap + 1, nslab = slab, ndh = dh, ndw = dw + 1;
+        if (ndw == 3) { ndw = 0; ++ndh; }
+        if (ntap == 9) { ntap = 0; ndh = 0; ++nslab; }
+        // K-step s + 2 (the weight stage that refills this slot)
+        int t2 = ntap + 1, s2 = nslab;
+        if (t2 == 9) { t2 = 0; ++s2; }
+        const bool refill = s + 2 < S;
+        // the slab after next: its patch goes where slab - 1 lived, one piece per K-step (taps 0..7 of this slab)
+        const bool ppiece = slab >= 1 && slab + 1 < a.kslabs && tap < MAXP;
+
+        read_half(a1, b1, st, buf, sh, 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < NTH; ++t) Mma<DT>::run(a0[t / MT], b0[t % MT], acc[t / MT][t % MT]);
+        __builtin_amdgcn_sched_barrier(0);
+        // this wave's reads of step s are back, its pieces of stage s + 1 (and any patch piece) have landed; after the
+        // barrier that holds for every wave, and ring slot st / the previous slab's patch are no longer read
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        read_half(a0, b0, st ^ 1, nslab & 1, ndh * WP + ndw, 0);
+        // second half: MFMA(a1, b1) with the DMA pieces of stage s + 2 tucked in
+        constexpr int MPG = NTH / (RW + 1);
+#pragma unroll
+        for (int g = 0; g < RW + 1; ++g) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (g < RW) { if (refill) issue_w_piece(st, t2, s2, g); }
+            else if (ppiece) {
+#pragma unroll
+                for (int i = 0; i < MAXP; ++i) if (i == tap) issue_patch_piece((slab + 1) & 1, slab + 1, i);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = g * MPG; t < (g + 1) * MPG; ++t) Mma<DT>::run(a1[t / MT], b1[t % MT], acc[t / MT][t % MT]);
+        }
+#pragma unroll
+        for (int t = (RW + 1) * MPG; t < NTH; ++t) Mma<DT>::run(a1[t / MT], b1[t % MT], acc[t / MT][t % MT]);
+        __builtin_amdgcn_sched_barrier(0);
+        tap = ntap; slab = nslab; dh = ndh; dw = ndw;
+    }
+    // last K-step
+    read_half(a1, b1, (S - 1) & 1, slab & 1, dh * WP + dw, 1);
+#pragma unroll
+    for (int t = 0; t < NTH; ++t) Mma<DT>::run(a0[t / MT], b0[t % MT], acc[t / MT][t % MT]);
+#pragma unroll
+    for (int t = 0; t < NTH; ++t) Mma<DT>::run(a1[t / MT], b1[t % MT], acc[t / MT][t % MT]);
+
+    // ---- epilogue: BN + ReLU + the one rounding, transposed through a per-wave patch (the patches / ring are dead),
+    // whole 128-byte rows out.  Padded position p = r * WP + c -> output pixel (h0 + r, c - 1); halo columns dropped.
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    OT* patch = reinterpret_cast<OT*>(smem) + wave * (16 * PROW);
+    f32x4 sc[NT], sf[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        sc[i] = *reinterpret_cast<const f32x4*>(a.scale + wn * 64 + i * 16 + fg * 4);
+        sf[i] = *reinterpret_cast<const f32x4*>(a.shift + wn * 64 + i * 16 + fg * 4);
+    }
+    char* obase = a.out + (((long long)frame * a.H + h0) * a.W) * a.out_ld * 2 + wn * 128;
+    const int rr = lane >> 3, cc = (lane & 7) * 8;
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            f32x4 v = acc[i][j] * sc[i] + sf[i];
+            if (a.relu) { v[0] = relu_f(v[0]); v[1] = relu_f(v[1]); v[2] = relu_f(v[2]); v[3] = relu_f(v[3]); }
+            Vec4<DT>::store(reinterpret_cast<char*>(patch + frow * PROW + i * 16 + fg * 4), v);
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int row = it * 8 + rr;
+            const int p = (wm * MT + j) * 16 + row;
+            const int r = (int)(((float)p + 0.5f) * a.inv_wp), c = p - r * WP;
+            const u32x4 o = *reinterpret_cast<const u32x4*>(patch + row * PROW + cc);
+            if (r < a.R && c >= 1 && c <= a.W && h0 + r < a.H)
+                __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(obase + (long long)(r * a.W + c - 1) * a.out_ld * 2 + cc * 2));
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <int DT, int WN, int WM>
+static int launch133g(const C133GArgs& a, hipStream_t stream) {
+    const int lds = 2 * a.prows * 128 + 2 * WN * 64 * 128;
+    AF_SET_MAX_LDS((&conv133g_kernel<DT, WN, WM>), 160 * 1024, "conv133g");
+    hipLaunchKernelGGL((conv133g_kernel<DT, WN, WM>), dim3(a.frames * a.upf), dim3(512), lds, stream, a);
+    AF_CHECK_LAUNCH("conv133g_kernel");
+    return AF_OK;
+}
+
+// rows of a frame one unit covers (0: the layer does not take this path)
+static int conv133g_rows(const af_conv_desc* d) {
+    if (d->dtype == AF_F32 || d->tpool) return 0;
+    if (d->kt != 1 || d->kh != 3 || d->kw != 3 || d->st != 1 || d->sh != 1 || d->sw != 1) return 0;
+    if (d->pt != 0 || d->ph != 1 || d->pw != 1) return 0;
+    if (d->cin % 64 != 0 || (d->cout != 128 && d->cout != 256)) return 0;
+    const int mpad = d->cout == 256 ? 224 : 448;               // positions of a unit: WM x 7 m-tiles
+    const int wp = d->w + 2;
+    int r = mpad / wp;
+    if (r > d->h) r = d->h;
+    if (r < 7) return 0;                                       // bands of >= 7 rows: the halo rows stay <= 2/7 of the patch
+    const int upf = (d->h + r - 1) / r;
+    r = (d->h + upf - 1) / upf;                                // even bands
+    const int prows = ((r + 2) * wp + 1 + 7) & ~7;
+    if (prows > 512 || 2 * prows * 128 + 2 * d->cout * 128 > 160 * 1024) return 0;
+    // worth it when the units fill the chip and most of a unit's positions are real
+    const long long units = (long long)d->n * d->t * upf;
+    if (units < 192 || units > 0x7fffffffLL) return 0;
+    if ((double)d->h * d->w / ((double)upf * mpad) < 0.6) return 0;
+    if ((long long)(d->h + 2) * d->w * d->cin * 2 >= (1LL << 31)) return 0;
+    return r;
+}
+
+bool conv133g_applies(const af_conv_desc* d, const void* residual, int out_ld) {
+    return !residual && (out_ld == 0 || out_ld % 8 == 0) && conv133g_rows(d) != 0;
+}
+
+int conv133g_run(const af_conv_desc* d, const void* in, const void* w_packed, const float* scale, const float* shift,
+                 void* out, int out_ld, hipStream_t stream) {
+    C133GArgs a;
+    a.in = (const char*)in; a.w = (const char*)w_packed; a.scale = scale; a.shift = shift; a.out = (char*)out;
+    a.H = d->h; a.W = d->w; a.Cin = d->cin; a.Cout = d->cout; a.frames = d->n * d->t;
+    a.R = conv133g_rows(d); a.upf = (d->h + a.R - 1) / a.R; a.WP = d->w + 2;
+    a.prows = ((a.R + 2) * a.WP + 1 + 7) & ~7;
+    a.kslabs = d->cin / 64; a.relu = d->relu; a.out_ld = out_ld ? out_ld : d->cout;
+    a.inv_wp = 1.0f / (float)a.WP;
+    if (d->cout == 256) return d->dtype == AF_BF16 ? launch133g<AF_BF16, 4, 2>(a, stream) : launch133g<AF_F16, 4, 2>(a, stream);
+    return d->dtype == AF_BF16 ? launch133g<AF_BF16, 2, 4>(a, stream) : launch133g<AF_F16, 2, 4>(a, stream);
+}
+
+}  // namespace af

@@ -205,6 +205,13 @@ CONV_CASES = [
     ("stream111_128to512_res_ragged", 128, 512, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 6, 107, 109), False, True),
     ("stream111_256to1024_res_ragged", 256, 1024, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 4, 91, 93), True, True),   # 32-channel wave columns
     ("stream111_64to768_three_columns", 64, 768, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 5, 95, 97), True, True),    # grid not a multiple of 8 x columns
+    # frame / band resident 1x3x3 (the s3 / s4 `b` convs at bench size: >= 192 work units): whole 14x14 frames, 256 channels,
+    # 1 and 3 K slabs (the third slab's patch is issued inside the loop); a 13-row frame; s3's 28x28 in two bands of 14
+    # rows; 27x26 (bands of 14 + 13 rows, narrower pitch); no ReLU
+    ("halo133_64to256_14x14", 64, 256, (1, 3, 3), (1, 1, 1), (0, 1, 1), (2, 100, 14, 14), True, False),
+    ("halo133_192to256_13x14", 192, 256, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 192, 13, 14), True, False),
+    ("halo133_128to128_28x28", 128, 128, (1, 3, 3), (1, 1, 1), (0, 1, 1), (2, 48, 28, 28), True, False),
+    ("halo133_256to128_27x26_norelu", 256, 128, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 100, 27, 26), False, False),
 ]
 EXPECT_VARIANT = {"tile256_1x3x3_res": 6, "tile256_ragged_m": 6, "tile512_1x3x3_res": 7, "tile512_ragged_m": 7,
                   "t311_64to64_T32": 8, "t311_256to64_T16": 8, "t311_256to64_T32_many": 8,
@@ -212,7 +219,10 @@ EXPECT_VARIANT = {"tile256_1x3x3_res": 6, "tile256_ragged_m": 6, "tile512_1x3x3_
                   "stream111_64to256_res": {"f32": 2, "f16": 10, "bf16": 10}, "stream111_64to256_ragged": {"f32": 2, "f16": 10, "bf16": 10},
                   "stream111_128to512_res_ragged": {"f32": 5, "f16": 10, "bf16": 10},
                   "stream111_256to1024_res_ragged": {"f32": 5, "f16": 10, "bf16": 10},
-                  "stream111_64to768_three_columns": {"f32": 2, "f16": 10, "bf16": 10}}
+                  "stream111_64to768_three_columns": {"f32": 2, "f16": 10, "bf16": 10},
+                  "halo133_64to256_14x14": {"f32": 6, "f16": 11, "bf16": 11}, "halo133_192to256_13x14": {"f32": 6, "f16": 11, "bf16": 11},
+                  "halo133_128to128_28x28": {"f32": 7, "f16": 11, "bf16": 11},
+                  "halo133_256to128_27x26_norelu": {"f32": 7, "f16": 11, "bf16": 11}}
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
