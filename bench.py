@@ -262,6 +262,99 @@ def bench_dualrun(args, rank, world, dev):
         dist.destroy_process_group()
 
 
+def bench_dualrun_rgb(args, rank, world, dev):
+    """BASELINE config[3]: "dualrun two-stream (rgb + temporal) model, batch=16 clips, 1xMI355X" as ONE step on the device:
+    AltFreezing forward of `--batch` uint8 clips (32x224x224, fused normalise prologue) -> its pooled 2048-vector (the RGB stream's
+    feature, feature.py:105-114) -> the tri-modal DualEncoderRGB (dualrun/model/dual_rgb.py: AU / landmark branch encoders over
+    8 frames + masked-mean RGB feature + rgb_proj + head) -> GatedMoE late fusion with the AltFreezing logit (rgb/engine_rgb.py:369-404).
+    value = clips/s.  Weights / AU / landmark tracks are synthetic (trained checkpoints and the LibreFace / MediaPipe extractors are
+    not available offline)."""
+    from af_mi355x import dualrun, synth
+    from af_mi355x.classifier import Classifier
+    B = args.batch
+    sdc = synth.synthetic_state_dict(seed=0)
+    clf = Classifier(precision=args.dtype)
+    clf.network.load_state_dict(sdc)
+    clf = clf.to(dev).eval()
+    sp = dualrun.DualSpec(36, 132, 256, 4, 4, 768, 0.7, 128)
+    sdd = dualrun.dual_rgb_synthetic_state_dict(sp, 2048, seed=0)
+    net = dualrun.DualEncoderRGB(36, 132, 2048, d_model=256, depth=4, heads=4, ff_dim=3.0, rgb_backbone=clf, rgb_from_features=False)
+    net.load_state_dict(sdd)
+    net = net.to(dev).eval()
+    moe = dualrun.GatedMoE().to(dev).eval()
+    u8 = synth.synthetic_clips_u8(B, seed=2026 + rank, kind="uniform")
+    A, L, lengths = dualrun.synthetic_dual_inputs(B, sp, frames=8, seed=2026 + rank)
+    ud, Ad, Ld = u8.to(dev), A.to(dev), L.to(dev)
+    mask = net.lengths_to_mask(lengths, 8, dev)
+    ms = {"altfreezing": 0.0, "dual_rgb": 0.0}
+
+    def step():
+        rgb = clf.network.forward_clips_u8(ud, return_pooled=True)
+        z_dual = net(Ad, Ld, rgb["pooled"].view(B, 1, -1), key_padding_mask=mask)        # V = the pooled feature: no second forward
+        return moe(rgb["final_output"], z_dual.view(B, 1)), rgb, z_dual
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    net.rgb_from_features = True
+    with torch.inference_mode():
+        for _ in range(args.warmup):
+            (z, gate), rgb, z_dual = step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            (z, gate), rgb, z_dual = step()
+        fence()
+        dt = time.perf_counter() - t0
+        # share of the AltFreezing forward in a step (events on the launch stream)
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        e[0].record(); rgb2 = clf.network.forward_clips_u8(ud, return_pooled=True); e[1].record()
+        net(Ad, Ld, rgb2["pooled"].view(B, 1, -1), key_padding_mask=mask); e[2].record()
+        torch.cuda.synchronize(dev)
+        ms["altfreezing"], ms["dual_rgb"] = e[0].elapsed_time(e[1]), e[1].elapsed_time(e[2])
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    line = {"metric": "clips/sec (dualrun two-stream: AltFreezing 32x3x224x224 + AU/LMK 8 frames)", "value": round(world * B * args.steps / dt, 2),
+            "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype + " (AltFreezing trunk) / f32 (dual encoder, head, MoE)",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE config[3]: AltFreezing i3d_ori forward (uint8 clips, fused prologue) -> pooled 2048-d feature -> "
+                                   "DualEncoderRGB (AU 36 + LMK 132 x 8 frames, d_model 256, 4 layers, ff 768; rgb_proj; 3d head) -> GatedMoE, "
+                                   "batch=%d clips/GPU, synthetic weights / tracks" % B,
+                       "global_batch": world * B, "parallelism": "dp%d" % world},
+            "stage_ms": {k: round(v, 3) for k, v in ms.items()}}
+    if rank == 0 and world == 1 and args.cpu_clips > 0:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import dualrun_oracle
+        import i3d_oracle
+        n = min(args.cpu_clips, B)
+        torch.set_num_threads(16)
+        x = i3d_oracle.normalize(u8[:n])
+        i3d_oracle.forward(sdc, x[:1])
+        t0 = time.perf_counter()
+        ref_logit, stages = i3d_oracle.forward(sdc, x, return_stages=True)
+        feat = stages["avgpool"].reshape(n, 1, -1)
+        ref_dual, _ = dualrun_oracle.dual_rgb_forward(sdd, A[:n], L[:n], feat, dualrun_oracle.lengths_to_mask(lengths[:n], 8), heads=4, tau=0.7)
+        msd = {k: v.detach().cpu() for k, v in moe.state_dict().items()}
+        ref_z, _ = dualrun_oracle.gated_moe(msd, ref_logit, ref_dual.view(n, 1))
+        tc = time.perf_counter() - t0
+        line["cpu_baseline"] = {"value": round(n / tc, 3), "unit": "clips/s", "cores": 16, "kind": "port",
+                                "sample": "%d clips, PyTorch CPU oracles (AltFreezing + DualEncoderRGB + GatedMoE restatements), fp32, 16 threads, 1 timed pass" % n}
+        line["max_abs_err_vs_cpu_fp32"] = {"altfreezing_logit": float((rgb["final_output"][:n].cpu() - ref_logit).abs().max()),
+                                           "dual_logit": float((z_dual[:n].cpu() - ref_dual).abs().max()),
+                                           "fused_logit": float((z[:n].cpu() - ref_z).abs().max())}
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def bench_aligner(args, rank, world, dev):
     """SURVEY 8f rank 5 on its own: FasterCropAlignXRay's warps for `--batch` clips of 32 tracked crops (~420x420) -> 224x224
     per GPU; value = clips/s with the crops and the fitted transforms already resident (the warp launches only); the
@@ -450,7 +543,7 @@ def main():
     ap.add_argument("--batch", type=int, default=16, help="clips per GPU")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--cpu-clips", type=int, default=4, help="clips in the CPU baseline sample (0 = skip)")
-    ap.add_argument("--model", default="i3d", choices=["i3d", "slowfast", "ftcn_tt", "dualrun", "aligner", "conv3x3x3"],
+    ap.add_argument("--model", default="i3d", choices=["i3d", "slowfast", "ftcn_tt", "dualrun", "dualrun_rgb", "aligner", "conv3x3x3"],
                     help="i3d = the i3d_ori plugin (BASELINE metric); slowfast = the two-pathway SlowFast-R50, ftcn_tt = the "
                          "reference's second plugin (next rows of SURVEY 8f)")
     ap.add_argument("--no-roofline", action="store_true")
@@ -478,6 +571,8 @@ def main():
 
     if args.model == "dualrun":
         return bench_dualrun(args, rank, world, dev)
+    if args.model == "dualrun_rgb":
+        return bench_dualrun_rgb(args, rank, world, dev)
     if args.model == "aligner":
         return bench_aligner(args, rank, world, dev)
     if args.model == "conv3x3x3":

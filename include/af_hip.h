@@ -172,6 +172,11 @@ int af_maxpool3d(const af_pool_desc* d, const void* in, void* out, void* stream)
  * nn.Linear that feature.py:105-114 hooks); logits: fp32 [n][to*ho*wo*num_classes]. */
 int af_avgpool_fc(const af_pool_desc* d, const void* in, const float* fc_w, const float* fc_b,
                   int num_classes, float* pooled, float* logits, void* stream);
+/* the same with the callers' score epilogue fused behind the Linear (ClassifierSvc.infer_scores, test/af_realtime.py:88-95;
+ * = TEST2.py:186-204, demo.py:328-331): scores[row] = sigmoid(logit) for num_classes == 1, softmax(logits)[1] for
+ * num_classes == 2 (fp32 [n * to*ho*wo]); scores may be NULL. */
+int af_avgpool_fc_scores(const af_pool_desc* d, const void* in, const float* fc_w, const float* fc_b,
+                         int num_classes, float* pooled, float* logits, float* scores, void* stream);
 
 /* The two halves of the head separately, for multi-pathway heads (SlowFast: one AvgPool3d per pathway, pooled
  * vectors concatenated by channel - head_helper.py:79-85 - then one Linear): af_avgpool writes row r of the pooled
@@ -180,6 +185,8 @@ int af_avgpool_fc(const af_pool_desc* d, const void* in, const float* fc_w, cons
 int af_avgpool(const af_pool_desc* d, const void* in, float* pooled, int pooled_ld, void* stream);
 int af_linear(const float* x, const float* w, const float* b, int rows, int in_features, int out_features,
               float* y, void* stream);
+int af_linear_scores(const float* x, const float* w, const float* b, int rows, int in_features, int out_features,
+                     float* y, float* scores, void* stream);
 
 /* ---- FTCN-TT plugin (reference model/classifier/i3d_temporal_var_fix_dropout_tt_cfg.py, time_transformer.py) ---- */
 
@@ -222,6 +229,19 @@ int af_dual_branch_encoders(int branches, const float* const* x, const float* co
 /* DualEncoderAU_LMK.head (:115-121): LayerNorm(n) -> Linear(n,n) -> GELU -> Linear(n,1) on z [clips][n];
  * weights: gamma, beta, W1^T [n][n], b1, w2 [n], b2. */
 int af_dual_head(const float* z, const float* weights, int clips, int n, float* logits, void* stream);
+
+/* dualrun tri-modal model (reference dualrun/model/dual_rgb.py).
+ * af_masked_mean_proj: AltFreezingRGBEncoder.forward with from_features (:27-44) + rgb_proj (:70, Linear without bias):
+ *   v [clips][tv][vis] per-frame / per-window RGB features (the AltFreezing backbone's pooled 2048-vector, feature.py:105-114);
+ *   lengths [clips] = valid frames of a key-padding mask over `tmask` frames (NULL: no mask = plain mean); tv == tmask, or
+ *   tv == 1 (broadcast against the mask like torch does); wt = rgb_proj.weight^T [vis][d];
+ *   z[clip * z_ld + 0..d) = (sum_t v[t] * valid[t] / max(sum valid, 1e-6)) @ wt.
+ * af_mlp_head: DualEncoderRGB.head (:75-79) = LayerNorm(n) -> Linear(n, hidden) -> GELU -> Linear(hidden, 1) on z [clips][n];
+ *   weights: gamma [n], beta [n], W1^T [n][hidden], b1 [hidden], w2 [hidden], b2; scores (optional) = sigmoid(logit).
+ *   (af_dual_head is the hidden == n case without scores.) */
+int af_masked_mean_proj(const float* v, int clips, int tv, int vis, const int* lengths, int tmask, const float* wt, int d,
+                        float* z, int z_ld, void* stream);
+int af_mlp_head(const float* z, const float* weights, int clips, int n, int hidden, float* logits, float* scores, void* stream);
 
 /* GatedMoE.forward (dualrun/rgb/engine_rgb.py:369-384): fuses the RGB (AltFreezing) logit and the dual-encoder logit of n
  * clips: gate = sigmoid(W2 relu(W1 [z_rgb, z_dual, |z_rgb - z_dual|] + b1) + b2), p = gate * sigmoid(z_rgb / max(t_rgb, 1))
@@ -281,6 +301,8 @@ typedef struct af_op {
     /* CONV only: split-K scratch (af_conv3d_bn_act) */
     void* workspace;
     int64_t workspace_bytes;
+    /* HEAD / LINEAR only: optional per-row scores (af_avgpool_fc_scores) */
+    float* scores;
 } af_op;
 
 /* Enqueue ops[0..n) in order on `stream` (AltFreezing: ResNet.forward, video_model_builder.py:561-578). */

@@ -85,3 +85,26 @@ def gated_moe(sd, z_rgb, z_dual):
     g = torch.sigmoid(F.linear(F.relu(F.linear(x, sd["gate.0.weight"], sd["gate.0.bias"])), sd["gate.2.weight"], sd["gate.2.bias"]))
     p = g * torch.sigmoid(z_rgb / sd["t_rgb"].clamp_min(1.0)) + (1 - g) * torch.sigmoid(z_dual / sd["t_dual"].clamp_min(0.1))
     return torch.log((p + 1e-6) / (1 - p + 1e-6)), g
+
+
+def dual_rgb_forward(sd, A, L, V, pad=None, heads=4, tau=0.7, dtype=torch.float32):
+    """DualEncoderRGB.forward (dualrun/model/dual_rgb.py:91-122) with AltFreezingRGBEncoder.from_features (:27-44):
+    (bin_logits (B,), z (B, 3D)).  ``pad``: (B,T) bool key-padding mask (True = padding) or None; ``tau`` = BranchEncoder's
+    default pool_tau 0.7 (the constructor does not pass one, :59-60)."""
+    A, L, V = A.to(dtype), L.to(dtype), V.to(dtype)
+    with torch.no_grad():
+        za = branch_encoder(A, sd, "au_enc", heads, tau, pad)
+        zl = branch_encoder(L, sd, "lmk_enc", heads, tau, pad)
+        if pad is None:
+            zv_clip = V.mean(dim=1)
+        else:
+            valid = (~pad).to(dtype)
+            w = (valid / valid.clamp_min(1e-6).sum(dim=1, keepdim=True)).unsqueeze(-1)
+            zv_clip = (V * w).sum(dim=1)
+        zv = F.linear(zv_clip, sd["rgb_proj.weight"].to(dtype))
+        z = torch.cat([za, zl, zv], dim=-1)
+        w_ = lambda k: sd[k].to(dtype)
+        y = F.layer_norm(z, (z.shape[-1],), w_("head.0.weight"), w_("head.0.bias"), 1e-5)
+        y = F.gelu(F.linear(y, w_("head.1.weight"), w_("head.1.bias")))
+        logits = F.linear(y, w_("head.4.weight"), w_("head.4.bias")).squeeze(-1)
+    return logits, z

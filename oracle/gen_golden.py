@@ -16,6 +16,8 @@ Fixtures
   f1b_logits.json   B=16 logits of BASELINE config[1]'s batch (W(0)) + 8 clips on the "hot" checkpoint W(3, hot), fp32/fp64
   f2_stages.npz     per-stage statistics + sampled activations for clip 0
   f3_kats.npz/.json per-layer-class known-answer tests on small tensors
+  f9_dualrgb.*      the reference's tri-modal DualEncoderRGB (dualrun/model/dual_rgb.py): logits fp32 / fp64, masked / unmasked /
+                    broadcast V
   f4_load.json      behaviour table of ``ModelBase.load`` on crafted checkpoints
 """
 import json
@@ -520,6 +522,53 @@ def synthetic_aligner_case(rng, frames, size, mirrored=False):
     return infos
 
 
+def gen_dualrun_rgb():
+    """F9: the reference's tri-modal ``DualEncoderRGB`` (dualrun/model/dual_rgb.py:47-122) with ``rgb_from_features=True``
+    (V = AltFreezing features, vis_dim 2048 = the i3d head's pooled vector), d_model 256, depth 4, heads 4 and
+    ``ff_dim = 3.0`` (the constructor forwards ff_dim into BranchEncoder's mlp_ratio slot: 3.0 gives the 768-wide layers of
+    checkpoints/test7/args.json).  Pure torch; imported as a two-file package so that its ``from .dual_encoder import``
+    resolves (the directory's own package name ``model`` would collide with altfreezing's)."""
+    import importlib.util
+    import types
+    from af_mi355x import dualrun
+    mdir = os.path.join(ref_import.REFERENCE_ROOT, "dualrun", "model")
+    pkg = types.ModuleType("ref_dualrun_model")
+    pkg.__path__ = [mdir]                                   # the package's own __init__ is not run
+    sys.modules["ref_dualrun_model"] = pkg
+    mod = importlib.import_module("ref_dualrun_model.dual_rgb")
+    vis = 2048
+    net = mod.DualEncoderRGB(au_dim=36, lmk_dim=132, vis_dim=vis, d_model=256, depth=4, heads=4, ff_dim=3.0, dropout=0.1,
+                             rgb_backbone=None, rgb_from_features=True).eval()
+    sp = dualrun.DualSpec(36, 132, 256, 4, 4, 768, 0.7, 128)
+    lay = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
+    assert lay == [(k, tuple(sh)) for k, sh in dualrun.dual_rgb_state_dict_layout(sp, vis)], "product DualEncoderRGB table disagrees with the reference"
+    sd = dualrun.dual_rgb_synthetic_state_dict(sp, vis, seed=WEIGHT_SEED)
+    net.load_state_dict(sd)
+    out = {}
+    for tag, batch, frames, tv, ragged in (("b6_t8", 6, 8, 8, True), ("b3_t8_nomask", 3, 8, 8, False), ("b4_t8_v1", 4, 8, 1, True)):
+        A, L, lengths = dualrun.synthetic_dual_inputs(batch, sp, frames=frames, seed=CLIP_SEED + 1)
+        gv = torch.Generator().manual_seed(CLIP_SEED + 77)
+        V = torch.rand((batch, tv, vis), generator=gv) * 2.0          # post-ReLU average-pooled features are non-negative
+        mask = net.lengths_to_mask(lengths, frames, torch.device("cpu")) if ragged else None
+        with torch.no_grad():
+            y32 = net(A, L, V, key_padding_mask=mask)
+        net.double()
+        with torch.no_grad():
+            y64 = net(A.double(), L.double(), V.double(), key_padding_mask=mask)
+        net.float()
+        out[tag + "_lengths"] = lengths.numpy().astype(np.int64) if ragged else np.array([-1])
+        out[tag + "_logits_f32"], out[tag + "_logits_f64"] = y32.numpy(), y64.numpy()
+        print("F9 dualrun rgb", tag, "logits", y32.numpy().round(5).tolist())
+    with open(os.path.join(GOLD, "f9_dualrgb.json"), "w") as f:
+        json.dump({"source": "reference dualrun/model/dual_rgb.py DualEncoderRGB(au 36, lmk 132, vis 2048, d_model 256, depth 4, heads 4, "
+                             "ff_dim 3.0, rgb_from_features True), eval, PyTorch CPU; weights dual_rgb_synthetic_state_dict(seed), "
+                             "inputs synthetic_dual_inputs(seed + 1), V = 2 * rand (generator seed + 77)",
+                   "num_keys": len(lay), "num_params": int(sum(p.numel() for p in net.parameters())),
+                   "weights_seed": WEIGHT_SEED, "inputs_seed": CLIP_SEED + 1,
+                   "weights_sha256": synth.state_dict_sha256(sd)}, f, indent=1)
+    np.savez_compressed(os.path.join(GOLD, "f9_dualrgb.npz"), **out)
+
+
 def gen_aligner():
     """F8: the similarity fit / landmark transform of the clip aligner (test_tools/warp_for_xray.py,
     test_tools/faster_crop_align_xray.py with images=None) - pure numpy in the reference.  Both files `import cv2` at the top;
@@ -562,6 +611,7 @@ def main():
     gen_f1b(clf)
     gen_slowfast()
     gen_dualrun()
+    gen_dualrun_rgb()
     gen_aligner()
 
 
@@ -573,6 +623,11 @@ if __name__ == "__main__":
         os.makedirs(GOLD, exist_ok=True)
         torch.set_num_threads(8)
         gen_dualrun()
+    elif "--dualrun-rgb" in sys.argv:
+        os.makedirs(GOLD, exist_ok=True)
+        torch.set_num_threads(8)
+        import importlib
+        gen_dualrun_rgb()
     elif "--f1b" in sys.argv:
         os.makedirs(GOLD, exist_ok=True)
         torch.manual_seed(0)

@@ -45,6 +45,7 @@ class Op(C.Structure):
         ("in_strides", C.c_int64 * 5),
         ("mean", C.c_float * 3), ("std_", C.c_float * 3),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
+        ("scores", C.c_void_p),
     ]
 
 
@@ -75,6 +76,11 @@ ABI = {
     "af_conv_variant_name": (C.c_char_p, [C.c_int]),
     "af_maxpool3d": (C.c_int, [C.POINTER(PoolDesc), C.c_void_p, C.c_void_p, C.c_void_p]),
     "af_avgpool_fc": (C.c_int, [C.POINTER(PoolDesc)] + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 3),
+    "af_avgpool_fc_scores": (C.c_int, [C.POINTER(PoolDesc)] + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 4),
+    "af_linear_scores": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "af_masked_mean_proj": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                      C.c_int, C.c_void_p]),
+    "af_mlp_head": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "af_avgpool": (C.c_int, [C.POINTER(PoolDesc), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "af_linear": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p, C.c_void_p]),
     "af_pack_tstem_weight": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

@@ -180,7 +180,7 @@ class I3D8x8(_HipNetwork):
         super().__init__(i3d_r50_spec(num_frames=clip_size, crop=crop_size), precision)
         self.clip_size, self.imsize = clip_size, imsize
 
-    def forward(self, images, noise=None, has_mask=None, freeze_backbone=False, return_feature_maps=False):
+    def forward(self, images, noise=None, has_mask=None, freeze_backbone=False, return_feature_maps=False, return_scores=False):
         assert not freeze_backbone
         x = self._check_input(images)
         B, _, T, H, W = x.shape
@@ -189,12 +189,24 @@ class I3D8x8(_HipNetwork):
         with torch.cuda.device(x.device):
             eng = self._engine(self._select_dtype(), B, (T, H, W), x.device)
             logits, pooled = eng.run_f32(x)
-            pred = self._finish(eng, logits, pooled, B)
-        return {"final_output": pred}
+            out = {"final_output": self._finish(eng, logits, pooled, B)}
+            if return_scores:                        # not a reference argument: the callers' sigmoid, from the head kernel
+                out["scores"] = self._scores_of(eng, B)
+        return out
 
-    def forward_clips_u8(self, clips_bthwc: torch.Tensor, mean=None, std=None):
+    @staticmethod
+    def _scores_of(eng, B):
+        if eng.scores is None or eng.head_positions != 1:
+            raise ValueError("scores are defined for a 1- or 2-class head on a crop with one head position")
+        return eng.scores.clone().view(B)
+
+    def forward_clips_u8(self, clips_bthwc: torch.Tensor, mean=None, std=None, return_scores=False, return_pooled=False):
         """Fused caller prologue: uint8 (B,T,H,W,3) 0..255 RGB clips straight from the aligner; replaces
-        as_tensor/permute/sub/div of ``ClassifierSvc.infer_scores`` (test/af_realtime.py:77-83)."""
+        as_tensor/permute/sub/div of ``ClassifierSvc.infer_scores`` (test/af_realtime.py:77-83).
+        ``return_scores`` adds ``"scores"``: (B,) sigmoid(logit) - or softmax[:,1] for a 2-class head - computed by the
+        head kernel itself (the callers' epilogue, af_realtime.py:88-95); ``return_pooled`` adds ``"pooled"``: the
+        (B, 2048) average-pooled feature that the head's Linear consumes (what feature.py:105-114 extracts with a hook
+        and dualrun's RGB stream consumes, dualrun/model/dual_rgb.py:27-44)."""
         from .synth import pixel_mean_std_f32
         if mean is None or std is None:
             m, s = pixel_mean_std_f32()
@@ -204,8 +216,25 @@ class I3D8x8(_HipNetwork):
         with torch.cuda.device(dev):
             eng = self._engine(self._select_dtype(), B, (T, H, W), dev)
             logits, pooled = eng.run_u8(clips_bthwc.contiguous(), mean, std)
-            pred = self._finish(eng, logits, pooled, B)
-        return {"final_output": pred}
+            out = {"final_output": self._finish(eng, logits, pooled, B)}
+            if return_scores:
+                out["scores"] = self._scores_of(eng, B)
+            if return_pooled:
+                out["pooled"] = pooled.clone().view(B, -1)
+        return out
+
+    def infer_scores(self, aligned_batch_bthwc, as_numpy: bool = True):
+        """``ClassifierSvc.infer_scores`` (test/af_realtime.py:75-96; = TEST2.py:151-204) as ONE op list: (B,T,H,W,C) RGB
+        0..255 clips (uint8 / float, numpy or tensor, any device) -> (B,) fake probabilities.  Normalisation, forward and
+        sigmoid all run on the GPU; only the B floats come back."""
+        x = torch.as_tensor(aligned_batch_bthwc)
+        dev = next(self.parameters()).device
+        if x.dtype == torch.uint8:                   # what the aligner hands over: normalisation fused into the input pack
+            s = self.forward_clips_u8(x.to(dev), return_scores=True)["scores"]
+        else:                                        # real-valued pixels: normalise like the callers (af_realtime.py:77-83)
+            from .synth import normalize_like_callers
+            s = self.forward(normalize_like_callers(x.to(dev)), return_scores=True)["scores"]
+        return s.float().cpu().numpy() if as_numpy else s
 
 
 class SlowFast8x8(_HipNetwork):

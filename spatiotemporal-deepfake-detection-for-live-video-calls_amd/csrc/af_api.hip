@@ -41,13 +41,13 @@ static int run_one(const af_op& op, hipStream_t s) {
         case AF_OP_MAXPOOL:
             return af_maxpool3d(&op.pool, op.in, op.out, s);
         case AF_OP_HEAD:
-            return af_avgpool_fc(&op.pool, op.in, (const float*)op.weight, op.scale, op.num_classes, (float*)op.aux,
-                                 (float*)op.out, s);
+            return af_avgpool_fc_scores(&op.pool, op.in, (const float*)op.weight, op.scale, op.num_classes, (float*)op.aux,
+                                        (float*)op.out, op.scores, s);
         case AF_OP_AVGPOOL:      /* out = pooled (+ channel offset), out_ld = pooled row stride */
             return af_avgpool(&op.pool, op.in, (float*)op.out, op.out_ld, s);
         case AF_OP_LINEAR:       /* in = x, weight = w, scale = bias, pool.n = rows, pool.c = in_features */
-            return af_linear((const float*)op.in, (const float*)op.weight, op.scale, op.pool.n, op.pool.c, op.num_classes,
-                             (float*)op.out, s);
+            return af_linear_scores((const float*)op.in, (const float*)op.weight, op.scale, op.pool.n, op.pool.c, op.num_classes,
+                                    (float*)op.out, op.scores, s);
         case AF_OP_PACK_F32:
             return af_pack_input_f32((const float*)op.in, op.conv.n, op.conv.t, op.conv.h, op.conv.w, op.in_strides[0],
                                      op.in_strides[1], op.in_strides[2], op.in_strides[3], op.in_strides[4],

@@ -246,8 +246,10 @@ __global__ __launch_bounds__(DUAL_THREADS) void dual_branch_kernel(const DualArg
     }
 }
 
-// head: LayerNorm(n) -> Linear(n, n) -> GELU -> Linear(n, 1);  flat weights: gamma, beta, W1^T [n][n], b1, w2, b2
-__global__ __launch_bounds__(256) void dual_head_kernel(const float* z, const float* w, int n, float* logits) {
+// head: LayerNorm(n) -> Linear(n, hidden) -> GELU -> Linear(hidden, 1) [-> sigmoid];  flat weights: gamma [n], beta [n],
+// W1^T [n][hidden], b1 [hidden], w2 [hidden], b2
+__global__ __launch_bounds__(256) void dual_head_kernel(const float* z, const float* w, int n, int hidden, float* logits,
+                                                        float* scores) {
     extern __shared__ float sm[];
     float* x = sm; float* y = sm + n; float* red = y + n;
     const int tid = threadIdx.x, clip = blockIdx.x;
@@ -267,17 +269,50 @@ __global__ __launch_bounds__(256) void dual_head_kernel(const float* z, const fl
     __syncthreads();
     for (int i = tid; i < n; i += 256) x[i] = (x[i] - mean) * rstd * w[i] + w[n + i];
     __syncthreads();
-    const float* W1t = w + 2 * n; const float* b1 = W1t + (long long)n * n; const float* w2 = b1 + n;
+    const float* W1t = w + 2 * n; const float* b1 = W1t + (long long)n * hidden; const float* w2 = b1 + hidden;
     float part = 0.f;
-    for (int j = tid; j < n; j += 256) {
+    for (int j = tid; j < hidden; j += 256) {
         float acc = b1[j];
-        for (int k = 0; k < n; ++k) acc = fmaf(x[k], W1t[(long long)k * n + j], acc);
+        for (int k = 0; k < n; ++k) acc = fmaf(x[k], W1t[(long long)k * hidden + j], acc);
         part = fmaf(gelu_erf(acc), w2[j], part);
     }
     red[tid] = part;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
-    if (tid == 0) logits[clip] = red[0] + w2[n];
+    if (tid == 0) {
+        const float l = red[0] + w2[hidden];
+        logits[clip] = l;
+        if (scores) scores[clip] = 1.f / (1.f + expf(-l));
+    }
+}
+
+// AltFreezingRGBEncoder.forward with from_features (dualrun/model/dual_rgb.py:27-44) + rgb_proj (:70, no bias):
+//   zv[b] = sum_t V[b][t] * w[b][t],  w = valid / max(sum valid, 1e-6)  (no mask: the plain mean over tv frames),
+//   z[b][0..d) = zv[b] @ Wt   (Wt = rgb_proj.weight^T, [vis][d])
+// `lengths` counts the valid frames of a mask over `tmask` frames; V has tv == tmask frames, or tv == 1 (broadcast over
+// the mask as torch does: the weights then sum to 1, or to 0 for a clip with no valid frame).  One workgroup per clip.
+__global__ __launch_bounds__(256) void masked_mean_proj_kernel(const float* v, int tv, int vis, const int* lengths, int tmask,
+                                                               const float* wt, int d, float* z, int z_ld) {
+    extern __shared__ float sm[];                       // [vis] pooled vector
+    const int tid = threadIdx.x, clip = blockIdx.x;
+    int nvalid = lengths ? lengths[clip] : tmask;
+    nvalid = nvalid < 0 ? 0 : (nvalid > tmask ? tmask : nvalid);
+    const float inv = lengths ? 1.f / fmaxf((float)nvalid, 1e-6f) : 1.f / (float)tv;
+    for (int k = tid; k < vis; k += 256) {
+        float s = 0.f;
+        if (tv == 1) s = lengths ? v[(long long)clip * vis + k] * ((float)nvalid * inv) : v[(long long)clip * vis + k];
+        else {
+            const int tend = lengths ? nvalid : tv;
+            for (int t = 0; t < tend; ++t) s = fmaf(v[((long long)clip * tv + t) * vis + k], inv, s);
+        }
+        sm[k] = s;
+    }
+    __syncthreads();
+    for (int j = tid; j < d; j += 256) {
+        float acc = 0.f;
+        for (int k = 0; k < vis; ++k) acc = fmaf(sm[k], wt[(long long)k * d + j], acc);
+        z[(long long)clip * z_ld + j] = acc;
+    }
 }
 
 // GatedMoE.forward (dualrun/rgb/engine_rgb.py:369-384): a 3 -> hidden -> 1 gate on (z_rgb, z_dual, |z_rgb - z_dual|) mixes the
@@ -361,12 +396,30 @@ extern "C" int af_dual_branch_encoders(int branches, const float* const* x, cons
     return AF_OK;
 }
 
-extern "C" int af_dual_head(const float* z, const float* weights, int clips, int n, float* logits, void* stream) {
+extern "C" int af_mlp_head(const float* z, const float* weights, int clips, int n, int hidden, float* logits, float* scores,
+                           void* stream) {
     using namespace af;
-    AF_REQUIRE(z && weights && logits && clips >= 0 && n >= 1 && n <= 4096, "dual_head: bad argument");
+    AF_REQUIRE(z && weights && logits && clips >= 0 && n >= 1 && n <= 4096 && hidden >= 1, "mlp_head: bad argument");
     if (clips == 0) return AF_OK;
-    hipLaunchKernelGGL(dual_head_kernel, dim3(clips), dim3(256), (2 * n + 256) * 4, (hipStream_t)stream, z, weights, n, logits);
+    hipLaunchKernelGGL(dual_head_kernel, dim3(clips), dim3(256), (2 * n + 256) * 4, (hipStream_t)stream, z, weights, n, hidden,
+                       logits, scores);
     AF_CHECK_LAUNCH("dual_head_kernel");
+    return AF_OK;
+}
+
+extern "C" int af_dual_head(const float* z, const float* weights, int clips, int n, float* logits, void* stream) {
+    return af_mlp_head(z, weights, clips, n, n, logits, nullptr, stream);
+}
+
+extern "C" int af_masked_mean_proj(const float* v, int clips, int tv, int vis, const int* lengths, int tmask, const float* wt,
+                                   int d, float* z, int z_ld, void* stream) {
+    using namespace af;
+    AF_REQUIRE(v && wt && z && clips >= 0 && tv >= 1 && vis >= 1 && vis <= 16384 && d >= 1 && z_ld >= d, "masked_mean_proj: bad argument");
+    AF_REQUIRE(tmask >= 1 && (tv == tmask || tv == 1), "masked_mean_proj: V has %d frames, the mask %d (equal, or 1 to broadcast)", tv, tmask);
+    if (clips == 0) return AF_OK;
+    hipLaunchKernelGGL(masked_mean_proj_kernel, dim3(clips), dim3(256), vis * 4, (hipStream_t)stream, v, tv, vis, lengths, tmask, wt,
+                       d, z, z_ld);
+    AF_CHECK_LAUNCH("masked_mean_proj_kernel");
     return AF_OK;
 }
 

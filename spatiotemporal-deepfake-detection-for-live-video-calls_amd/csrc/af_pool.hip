@@ -101,10 +101,13 @@ __global__ __launch_bounds__(256) void avgpool_kernel(const char* __restrict__ i
 }
 
 // nn.Linear on the pooled vector: logits[row][k] = dot(pooled[row], w[k]) + b[k]
+// `scores` (optional): the callers' score epilogue (test/af_realtime.py:88-95) - sigmoid(logit) for one class,
+// softmax(logits)[1] for two - one value per row
 __global__ void fc_kernel(const float* __restrict__ pooled, const float* __restrict__ w, const float* __restrict__ b,
-                          int C, int num_classes, float* __restrict__ logits) {   // pooled rows are C-contiguous
+                          int C, int num_classes, float* __restrict__ logits, float* __restrict__ scores) {   // pooled rows are C-contiguous
     __shared__ float red[4];
     const long long row = blockIdx.x;
+    float l0 = 0.f, l1 = 0.f;
     for (int k = 0; k < num_classes; ++k) {
         float s = 0.f;
         for (int c = threadIdx.x; c < C; c += blockDim.x) s += pooled[row * C + c] * w[(long long)k * C + c];
@@ -112,9 +115,15 @@ __global__ void fc_kernel(const float* __restrict__ pooled, const float* __restr
         for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
         __syncthreads();
-        if (threadIdx.x == 0) logits[row * num_classes + k] = red[0] + red[1] + red[2] + red[3] + b[k];
+        if (threadIdx.x == 0) {
+            const float l = red[0] + red[1] + red[2] + red[3] + b[k];
+            logits[row * num_classes + k] = l;
+            if (k == 0) l0 = l; else if (k == 1) l1 = l;
+        }
         __syncthreads();
     }
+    if (scores && threadIdx.x == 0)
+        scores[row] = num_classes == 1 ? 1.f / (1.f + expf(-l0)) : 1.f / (1.f + expf(l0 - l1));    // softmax([l0, l1])[1]
 }
 
 }  // namespace af
@@ -193,20 +202,32 @@ extern "C" int af_avgpool(const af_pool_desc* d, const void* in, float* pooled, 
     return launch_avgpool(d, in, pooled, pooled_ld, (hipStream_t)stream);
 }
 
-extern "C" int af_linear(const float* x, const float* w, const float* b, int rows, int in_features, int out_features,
-                         float* y, void* stream) {
+extern "C" int af_linear_scores(const float* x, const float* w, const float* b, int rows, int in_features, int out_features,
+                                float* y, float* scores, void* stream) {
     AF_REQUIRE(x && w && b && y && rows > 0 && in_features > 0 && out_features > 0, "linear: bad argument");
-    hipLaunchKernelGGL(fc_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, w, b, in_features, out_features, y);
+    AF_REQUIRE(!scores || out_features == 1 || out_features == 2, "linear: scores are defined for 1 (sigmoid) or 2 (softmax[:,1]) classes, got %d",
+               out_features);
+    hipLaunchKernelGGL(fc_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, w, b, in_features, out_features, y, scores);
     AF_CHECK_LAUNCH("fc_kernel");
     return AF_OK;
 }
 
-extern "C" int af_avgpool_fc(const af_pool_desc* d, const void* in, const float* fc_w, const float* fc_b,
-                             int num_classes, float* pooled, float* logits, void* stream) {
+extern "C" int af_linear(const float* x, const float* w, const float* b, int rows, int in_features, int out_features,
+                         float* y, void* stream) {
+    return af_linear_scores(x, w, b, rows, in_features, out_features, y, nullptr, stream);
+}
+
+extern "C" int af_avgpool_fc_scores(const af_pool_desc* d, const void* in, const float* fc_w, const float* fc_b,
+                                    int num_classes, float* pooled, float* logits, float* scores, void* stream) {
     AF_REQUIRE(in && fc_w && fc_b && pooled && logits && num_classes > 0, "avgpool_fc: null argument");
     int rc = check_avgpool(d, "avgpool_fc");
     if (rc) return rc;
     rc = launch_avgpool(d, in, pooled, d->c, (hipStream_t)stream);
     if (rc) return rc;
-    return af_linear(pooled, fc_w, fc_b, d->n * d->to * d->ho * d->wo, d->c, num_classes, logits, stream);
+    return af_linear_scores(pooled, fc_w, fc_b, d->n * d->to * d->ho * d->wo, d->c, num_classes, logits, scores, stream);
+}
+
+extern "C" int af_avgpool_fc(const af_pool_desc* d, const void* in, const float* fc_w, const float* fc_b,
+                             int num_classes, float* pooled, float* logits, void* stream) {
+    return af_avgpool_fc_scores(d, in, fc_w, fc_b, num_classes, pooled, logits, nullptr, stream);
 }

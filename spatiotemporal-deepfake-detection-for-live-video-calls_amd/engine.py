@@ -345,6 +345,9 @@ class Engine:
         self.head_positions = self.head_dims[0] * self.head_dims[1] * self.head_dims[2]
         self.pooled = torch.empty((batch, self.head_positions, self.head_width), dtype=torch.float32, device=device)
         self.logits = torch.empty((batch, self.head_positions * spec.num_classes), dtype=torch.float32, device=device)
+        # the callers' score epilogue (sigmoid / softmax[:,1], test/af_realtime.py:88-95) rides behind the head's Linear
+        self.scores = (torch.empty((batch, self.head_positions), dtype=torch.float32, device=device)
+                       if spec.num_classes in (1, 2) else None)
 
         n_pack = len(self.inputs)
         self.n_ops = n_pack + len(plan.entries) + (self.TT_HEAD_OPS - 1 if isinstance(spec, FtcnTTSpec) else 0)
@@ -430,6 +433,7 @@ class Engine:
                 op.scale = weights.fc_b.data_ptr()
                 op.aux = self.pooled.data_ptr()
                 op.out = self.logits.data_ptr()
+                op.scores = self.scores.data_ptr() if self.scores is not None else None
                 op.num_classes = spec.num_classes
                 self.op_names.append("head")
                 self.op_macs.append(0)
@@ -448,6 +452,7 @@ class Engine:
                 op.pool.n, op.pool.c = batch * self.head_positions, self.head_width
                 op.num_classes = spec.num_classes
                 op.out = self.logits.data_ptr()
+                op.scores = self.scores.data_ptr() if self.scores is not None else None
                 self.op_names.append("head_linear")
                 self.op_macs.append(0)
             else:
@@ -548,6 +553,7 @@ class Engine:
         op.pool.n, op.pool.c = batch, dim
         op.num_classes = spec.num_classes
         op.out = self.logits.data_ptr()
+        op.scores = self.scores.data_ptr() if self.scores is not None else None
         assert i[0] - first == self.TT_HEAD_OPS
 
     # -- input binding -------------------------------------------------------------------------------------

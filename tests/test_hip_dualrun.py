@@ -81,3 +81,98 @@ def test_gated_moe_matches_reference():
     np.testing.assert_allclose(g.cpu().numpy(), st["moe_gate"], rtol=1e-5, atol=1e-6)
     with pytest.raises(RuntimeError):
         moe(torch.zeros(2, 1), torch.zeros(2, 1))
+
+
+# ---- tri-modal DualEncoderRGB (reference dualrun/model/dual_rgb.py:47-122), golden F9 ---------------------------------
+RGB_CASES = [("b6_t8", 6, 8, 8), ("b3_t8_nomask", 3, 8, 8), ("b4_t8_v1", 4, 8, 1)]
+
+
+def rgb_case(g, sp, tag, batch, frames, tv, vis=2048):
+    """inputs of a golden F9 case, regenerated from the seeds recorded in f9_dualrgb.json (gen_golden.gen_dualrun_rgb)"""
+    st = load_npz("f9_dualrgb.npz")
+    A, L, _ = dualrun.synthetic_dual_inputs(batch, sp, frames=frames, seed=g["inputs_seed"])
+    V = torch.rand((batch, tv, vis), generator=torch.Generator().manual_seed(g["inputs_seed"] - 1 + 77)) * 2.0
+    ln = st[tag + "_lengths"]
+    lengths = None if ln[0] < 0 else torch.from_numpy(ln)
+    return A, L, V, lengths, st[tag + "_logits_f32"]
+
+
+@pytest.fixture(scope="module")
+def dual_rgb():
+    g = load_json("f9_dualrgb.json")
+    sp = dualrun.DualSpec(36, 132, 256, 4, 4, 768, 0.7, 128)
+    sd = dualrun.dual_rgb_synthetic_state_dict(sp, 2048, seed=g["weights_seed"])
+    assert synth.state_dict_sha256(sd) == g["weights_sha256"] and len(sd) == g["num_keys"]
+    net = dualrun.DualEncoderRGB(au_dim=36, lmk_dim=132, vis_dim=2048, d_model=256, depth=4, heads=4, ff_dim=3.0)
+    net.load_state_dict(sd)
+    return g, sp, sd, net.cuda().eval()
+
+
+@pytest.mark.parametrize("tag,batch,frames,tv", RGB_CASES)
+def test_dual_rgb_matches_reference(dual_rgb, tag, batch, frames, tv):
+    g, sp, sd, net = dual_rgb
+    A, L, V, lengths, want = rgb_case(g, sp, tag, batch, frames, tv)
+    mask = None if lengths is None else net.lengths_to_mask(lengths, frames, "cuda")
+    with torch.inference_mode():
+        y, s = net(A.cuda(), L.cuda(), V.cuda(), key_padding_mask=mask, return_scores=True)
+        y2 = net(A.cuda(), L.cuda(), V.cuda(), key_padding_mask=mask)
+    assert y.shape == (batch,) and torch.equal(y, y2)
+    np.testing.assert_allclose(y.cpu().numpy(), want, rtol=0, atol=3e-5)
+    np.testing.assert_allclose(s.cpu().numpy(), torch.sigmoid(torch.from_numpy(want)).numpy(), rtol=0, atol=1e-5)
+
+
+def test_dual_rgb_vs_oracle_and_contract(dual_rgb):
+    g, sp, sd, net = dual_rgb
+    A, L, lengths = dualrun.synthetic_dual_inputs(16, sp, frames=8, seed=5)        # config[3] batch
+    V = torch.rand((16, 8, 2048), generator=torch.Generator().manual_seed(9)) * 2.0
+    pad = dualrun_oracle.lengths_to_mask(lengths, 8)
+    want, _ = dualrun_oracle.dual_rgb_forward(sd, A, L, V, pad, heads=4, tau=0.7)
+    with torch.inference_mode():
+        y = net(A.cuda(), L.cuda(), V.cuda(), key_padding_mask=pad.cuda())
+    np.testing.assert_allclose(y.cpu().numpy(), want.numpy(), rtol=0, atol=3e-5)
+    with pytest.raises(ValueError, match="suffix"):
+        bad = pad.clone(); bad[0, 0] = True; bad[0, 1] = False
+        net(A.cuda(), L.cuda(), V.cuda(), key_padding_mask=bad.cuda())
+    with pytest.raises(RuntimeError):
+        net(A, L, V)                                                               # CPU tensors: no fallback
+    with pytest.raises(NotImplementedError):
+        net(A.cuda(), L.cuda(), V.cuda(), return_seq=True)
+    with pytest.raises(ValueError, match="mlp_ratio"):
+        dualrun.DualEncoderRGB(36, 132, 2048)                                      # upstream's default ff_dim=768: 196 608-wide layers
+
+
+def test_two_stream_model_as_one_unit(dual_rgb):
+    """BASELINE config[3] shape: AltFreezing (shrunken clip, fp32) -> pooled 2048-vector -> DualEncoderRGB -> GatedMoE with the
+    AltFreezing logit, everything on the device; each stage against its oracle."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import i3d_oracle
+    from af_mi355x.arch import i3d_r50_spec
+    from af_mi355x.classifier import Classifier
+    g, sp, sd, net = dual_rgb
+    clip_size, size, B = 8, 64, 4
+    sdc = synth.synthetic_state_dict(i3d_r50_spec(clip_size, size), seed=5)
+    clf = Classifier(clip_size=clip_size, precision="f32", crop_size=size)
+    clf.network.load_state_dict(sdc)
+    clf = clf.cuda().eval()
+    u8 = synth.synthetic_clips_u8(B, seed=9, kind="smooth", num_frames=clip_size, size=size)
+    A, L, lengths = dualrun.synthetic_dual_inputs(B, sp, frames=8, seed=6)
+    net.rgb_backbone[0], net.rgb_from_features = clf, False
+    try:
+        mask = net.lengths_to_mask(lengths, 8, "cuda")
+        with torch.inference_mode():
+            rgb = clf.network.forward_clips_u8(u8.cuda(), return_scores=True, return_pooled=True)
+            z_dual = net(A.cuda(), L.cuda(), u8.cuda(), key_padding_mask=mask)
+            moe = dualrun.GatedMoE().cuda().eval()
+            z, gate = moe(rgb["final_output"], z_dual.view(B, 1))
+    finally:
+        net.rgb_backbone[0], net.rgb_from_features = None, True
+    x = synth.normalize_like_callers(u8)
+    want_logit, stages = i3d_oracle.forward(sdc, x, num_frames=clip_size, crop=size, return_stages=True)
+    feat = stages["avgpool"].reshape(B, 1, -1)
+    assert (rgb["pooled"].cpu() - feat.view(B, -1)).abs().max().item() <= 1e-4
+    assert (rgb["scores"].cpu() - i3d_oracle.scores(want_logit)).abs().max().item() <= 1e-5
+    want_dual, _ = dualrun_oracle.dual_rgb_forward(sd, A, L, feat, dualrun_oracle.lengths_to_mask(lengths, 8), heads=4, tau=0.7)
+    np.testing.assert_allclose(z_dual.cpu().numpy(), want_dual.numpy(), rtol=0, atol=1e-4)
+    msd = {k: v.detach().cpu() for k, v in moe.state_dict().items()}
+    wz, wg = dualrun_oracle.gated_moe(msd, want_logit, want_dual.view(B, 1))
+    np.testing.assert_allclose(z.cpu().numpy(), wz.numpy(), rtol=0, atol=2e-4)

@@ -331,3 +331,19 @@ def test_engine_cache_is_bounded(weights0):
     assert torch.allclose(ys[1][0], ys[5][0], atol=2e-3)
     clf.network.invalidate_packed()
     assert not clf.network._engines and not clf.network._packed
+
+
+def test_infer_scores_matches_callers_epilogue(clf32, weights0):
+    """ClassifierSvc.infer_scores (test/af_realtime.py:75-96): uint8 (B,T,H,W,C) clips -> sigmoid(logit), the sigmoid computed by
+    the head kernel; numpy in / numpy out like the reference, and the real-valued-pixel path through the callers' normalisation."""
+    u8 = synth.synthetic_clips_u8(2, seed=41, kind="smooth")
+    want = oracle.scores(oracle.forward(weights0, oracle.normalize(u8)))
+    s = clf32.network.infer_scores(u8.numpy())
+    assert isinstance(s, np.ndarray) and s.shape == (2,) and s.dtype == np.float32
+    assert np.abs(s - want.numpy()).max() <= 1e-5
+    s2 = clf32.network.infer_scores(u8.float() + 0.25, as_numpy=False)              # non-integral pixels: fp32 path
+    want2 = oracle.scores(oracle.forward(weights0, synth.normalize_like_callers(u8.float() + 0.25)))
+    assert s2.is_cuda and (s2.cpu() - want2).abs().max().item() <= 1e-5
+    with torch.inference_mode():
+        out = clf32.network.forward_clips_u8(u8.cuda(), return_scores=True, return_pooled=True)
+    assert out["pooled"].shape == (2, 2048) and torch.allclose(out["scores"], torch.sigmoid(out["final_output"]).view(2), atol=1e-6)

@@ -237,3 +237,24 @@ def test_hot_checkpoint_logits_match_reference():
 
 def hot_clips(f1b):
     return torch.cat([synth.synthetic_clips_u8(n, seed=seed, kind=kind) for kind, seed, n in f1b["clips"]])
+
+
+def test_dualrun_rgb_oracle_matches_reference():
+    """F9: the tri-modal DualEncoderRGB restatement (oracle/dualrun_oracle.dual_rgb_forward) against the reference class."""
+    import dualrun_oracle
+    from af_mi355x import dualrun
+    g = load_json("f9_dualrgb.json")
+    st = load_npz("f9_dualrgb.npz")
+    sp = dualrun.DualSpec(36, 132, 256, 4, 4, 768, 0.7, 128)
+    sd = dualrun.dual_rgb_synthetic_state_dict(sp, 2048, seed=g["weights_seed"])
+    assert synth.state_dict_sha256(sd) == g["weights_sha256"]
+    assert [k for k, _ in dualrun.dual_rgb_state_dict_layout(sp, 2048)] == list(sd) and len(sd) == g["num_keys"] == 129
+    for tag, batch, frames, tv in (("b6_t8", 6, 8, 8), ("b3_t8_nomask", 3, 8, 8), ("b4_t8_v1", 4, 8, 1)):
+        A, L, _ = dualrun.synthetic_dual_inputs(batch, sp, frames=frames, seed=g["inputs_seed"])
+        V = torch.rand((batch, tv, 2048), generator=torch.Generator().manual_seed(g["inputs_seed"] - 1 + 77)) * 2.0
+        ln = st[tag + "_lengths"]
+        pad = None if ln[0] < 0 else dualrun_oracle.lengths_to_mask(torch.from_numpy(ln), frames)
+        y, _ = dualrun_oracle.dual_rgb_forward(sd, A, L, V, pad, heads=4, tau=0.7)
+        np.testing.assert_allclose(y.numpy(), st[tag + "_logits_f32"], rtol=0, atol=2e-5)
+        y64, _ = dualrun_oracle.dual_rgb_forward(sd, A, L, V, pad, heads=4, tau=0.7, dtype=torch.float64)
+        np.testing.assert_allclose(y64.numpy(), st[tag + "_logits_f64"], rtol=0, atol=1e-7)
