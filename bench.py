@@ -494,7 +494,7 @@ def bench_conv3x3x3(args, rank, world, dev):
     tot_flop = sum(s["gflop_per_launch"] for s in shapes)
     tot_ms = sum(s["us_per_launch"] for s in shapes) / 1e3
     line = {"metric": "MFMA % on 3x3x3 Conv3d (synthetic: not a layer of the reference model)",
-            "value": round(100 * tot_flop / tot_ms / 1e3 / PEAK_TFLOPS[args.dtype], 2), "unit": "%% of dense %s MFMA peak (%.0f TFLOP/s)"
+            "value": round(100 * tot_flop / tot_ms / PEAK_TFLOPS[args.dtype], 2), "unit": "%% of dense %s MFMA peak (%.0f TFLOP/s)"
             % (args.dtype, PEAK_TFLOPS[args.dtype]), "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(tot_ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
             "data": "synthetic",
