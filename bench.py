@@ -107,7 +107,11 @@ def roofline_report(eng, args, line, reps=5):
     per_kernel, per_class, eng_bytes, kernel_ops, variants = {}, {}, {}, {}, {}
     for i in range(eng.n_ops):
         op = eng.ops[i]
-        if op.kind in (_lib.AF_OP_CONV, _lib.AF_OP_STEM, _lib.AF_OP_CONV_DUAL, _lib.AF_OP_STEM_POOL, _lib.AF_OP_TSTEM):
+        if op.kind == _lib.AF_OP_CONV_BC:                # b input + c output + residual + both weights; the b output stays on chip
+            cb, cc_ = op.conv, op.conv2
+            pos = cb.n * cb.to * cb.ho * cb.wo
+            eng_bytes[i] = es * (pos * cb.cin + pos * cc_.cout * (2 if op.residual else 1) + cb.cout * cb.cin * 9 + cc_.cout * cc_.cin)
+        elif op.kind in (_lib.AF_OP_CONV, _lib.AF_OP_STEM, _lib.AF_OP_CONV_DUAL, _lib.AF_OP_STEM_POOL, _lib.AF_OP_TSTEM):
             cd = op.conv
             mm = cd.n * cd.to * cd.ho * cd.wo
             if op.kind == _lib.AF_OP_STEM_POOL:          # only the pooled tensor is written
@@ -126,6 +130,8 @@ def roofline_report(eng, args, line, reps=5):
         if op.kind in (_lib.AF_OP_CONV, _lib.AF_OP_CONV_DUAL):
             d2 = C.byref(op.conv2) if op.kind == _lib.AF_OP_CONV_DUAL else None
             kname = _lib.lib.af_conv_variant_name(_lib.lib.af_conv_variant(C.byref(op.conv), d2)).decode()
+        elif op.kind == _lib.AF_OP_CONV_BC:
+            kname = "conv133g<b + c fused>"
         elif op.kind in (_lib.AF_OP_STEM, _lib.AF_OP_STEM_POOL, _lib.AF_OP_TSTEM):
             kname = {_lib.AF_OP_STEM: "stem_kernel", _lib.AF_OP_STEM_POOL: "stem_pool_kernel",
                      _lib.AF_OP_TSTEM: "tstem_kernel"}[op.kind]
@@ -144,8 +150,8 @@ def roofline_report(eng, args, line, reps=5):
             row = {"i": i, "name": eng.op_names[i], "class": TAG_NAMES[op.tag], "ms": round(ms[i], 4)}
             if i in eng_bytes:
                 cd = op.conv
-                row.update({"M": cd.n * cd.to * cd.ho * cd.wo, "N": cd.cout,
-                            "K": cd.cin * cd.kt * cd.kh * cd.kw + (op.conv2.cin if op.kind == _lib.AF_OP_CONV_DUAL else 0),
+                row.update({"M": cd.n * cd.to * cd.ho * cd.wo, "N": op.conv2.cout if op.kind == _lib.AF_OP_CONV_BC else cd.cout,
+                            "K": cd.cin * cd.kt * cd.kh * cd.kw + (op.conv2.cin if op.kind in (_lib.AF_OP_CONV_DUAL, _lib.AF_OP_CONV_BC) else 0),
                             "tflops": round(2 * eng.op_macs[i] / ms[i] / 1e9, 1),
                             "alg_GBs": round(eng_bytes[i] / ms[i] / 1e6, 0)})
             rows.append(row)

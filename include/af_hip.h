@@ -158,6 +158,16 @@ int af_conv3d_dual_bn_act(const af_conv_desc* d, const void* in, const void* w_p
                           const af_conv_desc* d2, const void* in2, const void* w2_packed,
                           const float* scale, const float* shift, void* out, int out_ld, void* stream);
 
+/* The 1x3x3 `b` conv (+BN+ReLU) and the 1x1x1 `c` conv (+BN) of a bottleneck + the ResBlock's residual add + ReLU
+ * (resnet_helper.py:283-325, 438-444) as ONE launch: relu( bn_c(conv_c( relu(bn_b(conv_b(in))) )) + residual ).  The b
+ * output of a frame (or band of rows) stays in LDS as the c conv's operand and never reaches HBM.  Available for the shapes
+ * af_conv_bc_fusable() accepts (16-bit, stride 1, 128 or 256 mid channels, enough frames to fill the chip: the s3 / s4
+ * bottlenecks at batch >= 12); `dc` describes the c conv over b's output ([n][t][h][w][db->cout]); `residual` may be NULL. */
+int af_conv_bc_fusable(const af_conv_desc* db, const af_conv_desc* dc);
+int af_conv3d_bc_bn_act(const af_conv_desc* db, const void* in, const void* wb_packed, const float* scale_b, const float* shift_b,
+                        const af_conv_desc* dc, const void* wc_packed, const float* scale_c, const float* shift_c,
+                        const void* residual, void* out, int out_ld, void* stream);
+
 /* which tile variant af_conv3d_[dual_]bn_act launches for `d` (+ optional `d2`) (>= 0) and its kernel name:
  * lets a profiler attribute per-layer device time and FLOPs to a kernel instantiation (bench.py roofline). */
 int af_conv_variant(const af_conv_desc* d, const af_conv_desc* d2);
@@ -275,7 +285,10 @@ int af_warp_affine_clip_u8(const void* crops, const af_align_frame* frames, int 
 enum af_op_kind { AF_OP_STEM = 0, AF_OP_CONV = 1, AF_OP_MAXPOOL = 2, AF_OP_HEAD = 3,
                   AF_OP_PACK_F32 = 4, AF_OP_PACK_U8 = 5, AF_OP_CONV_DUAL = 6, AF_OP_STEM_POOL = 7, AF_OP_AVGPOOL = 8, AF_OP_LINEAR = 9,
                   /* FTCN-TT: in/weight/scale/shift/out as commented in af_run_ops' switch (csrc/af_api.hip) */
-                  AF_OP_TSTEM = 10, AF_OP_TOKENS = 11, AF_OP_LAYERNORM = 12, AF_OP_ATTENTION = 13, AF_OP_GELU = 14 };
+                  AF_OP_TSTEM = 10, AF_OP_TOKENS = 11, AF_OP_LAYERNORM = 12, AF_OP_ATTENTION = 13, AF_OP_GELU = 14,
+                  /* b + c of a bottleneck in one launch: conv / weight / scale / shift = the b conv, conv2 / weight2 / scale2 /
+                     shift2 = the c conv, residual, out, out_ld (af_conv3d_bc_bn_act) */
+                  AF_OP_CONV_BC = 15 };
 
 typedef struct af_op {
     int32_t kind;                    /* af_op_kind */
@@ -303,6 +316,9 @@ typedef struct af_op {
     int64_t workspace_bytes;
     /* HEAD / LINEAR only: optional per-row scores (af_avgpool_fc_scores) */
     float* scores;
+    /* CONV_BC only: BatchNorm of the second (c) conv */
+    const float* scale2;
+    const float* shift2;
 } af_op;
 
 /* Enqueue ops[0..n) in order on `stream` (AltFreezing: ResNet.forward, video_model_builder.py:561-578). */

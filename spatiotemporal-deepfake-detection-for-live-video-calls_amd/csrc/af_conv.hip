@@ -764,6 +764,25 @@ extern "C" int af_conv3d_bn_act(const af_conv_desc* d, const void* in, const voi
     return conv_common(d, in, w_packed, nullptr, nullptr, nullptr, scale, shift, residual, out, out_ld, workspace, workspace_bytes, stream);
 }
 
+extern "C" int af_conv_bc_fusable(const af_conv_desc* db, const af_conv_desc* dc) {
+    return af::conv133g_fused_applies(db, dc, 0) ? 1 : 0;
+}
+
+extern "C" int af_conv3d_bc_bn_act(const af_conv_desc* db, const void* in, const void* wb_packed, const float* scale_b,
+                                   const float* shift_b, const af_conv_desc* dc, const void* wc_packed, const float* scale_c,
+                                   const float* shift_c, const void* residual, void* out, int out_ld, void* stream) {
+    using namespace af;
+    AF_REQUIRE(db && dc && in && wb_packed && scale_b && shift_b && wc_packed && scale_c && shift_c && out, "conv_bc: null argument");
+    AF_REQUIRE(aligned16(in) && aligned16(wb_packed) && aligned16(wc_packed) && aligned16(scale_b) && aligned16(shift_b) &&
+                   aligned16(scale_c) && aligned16(shift_c) && aligned16(residual) && aligned16(out), "conv_bc: buffers must be 16-byte aligned");
+    AF_REQUIRE(db->to == db->t && db->ho == db->h && db->wo == db->w && dc->to == dc->t && dc->ho == dc->h && dc->wo == dc->w,
+               "conv_bc: both convolutions keep the spatial size");
+    AF_REQUIRE(conv133g_fused_applies(db, dc, out_ld),
+               "conv_bc: this (1x3x3, 1x1x1) pair does not take the fused path (ask af_conv_bc_fusable first)");
+    return conv133g_fused_run(db, in, wb_packed, scale_b, shift_b, dc, wc_packed, scale_c, shift_c, residual, out, out_ld,
+                              (hipStream_t)stream);
+}
+
 extern "C" int af_conv3d_dual_bn_act(const af_conv_desc* d, const void* in, const void* w_packed,
                                      const af_conv_desc* d2, const void* in2, const void* w2_packed, const float* scale,
                                      const float* shift, void* out, int out_ld, void* stream) {

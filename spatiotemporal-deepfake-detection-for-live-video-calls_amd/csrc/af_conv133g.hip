@@ -32,9 +32,15 @@ struct C133GArgs {
     int kslabs;          // Cin / 64
     int relu, out_ld;
     float inv_wp;
+    // fused `c` conv (FUSEC instantiations): out = relu(bn2(conv1x1x1(b_out)) + res), b_out never leaves LDS
+    const char* w2;      // packed [Cout2][1][Cout]
+    const float* scale2;
+    const float* shift2;
+    const char* res;     // [frames][H][W][Cout2] or null
+    int Cout2, relu2;
 };
 
-template <int DT, int WN, int WM>
+template <int DT, int WN, int WM, bool FUSEC>
 __global__ __launch_bounds__(512, 2) void conv133g_kernel(const C133GArgs a) {
     typedef Elem<DT> E;
     typedef typename E::type OT;
@@ -179,46 +185,141 @@ __global__ __launch_bounds__(512, 2) void conv133g_kernel(const C133GArgs a) {
 #pragma unroll
     for (int t = 0; t < NTH; ++t) Mma<DT>::run(a1[t / MT], b1[t % MT], acc[t / MT][t % MT]);
 
-    // ---- epilogue: BN + ReLU + the one rounding, transposed through a per-wave patch (the patches / ring are dead),
-    // whole 128-byte rows out.  Padded position p = r * WP + c -> output pixel (h0 + r, c - 1); halo columns dropped.
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    OT* patch = reinterpret_cast<OT*>(smem) + wave * (16 * PROW);
+    __builtin_amdgcn_s_barrier();                      // every wave is done with the patches and the ring
     f32x4 sc[NT], sf[NT];
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
         sc[i] = *reinterpret_cast<const f32x4*>(a.scale + wn * 64 + i * 16 + fg * 4);
         sf[i] = *reinterpret_cast<const f32x4*>(a.shift + wn * 64 + i * 16 + fg * 4);
     }
-    char* obase = a.out + (((long long)frame * a.H + h0) * a.W) * a.out_ld * 2 + wn * 128;
     const int rr = lane >> 3, cc = (lane & 7) * 8;
+    if (!FUSEC) {
+        // ---- epilogue: BN + ReLU + the one rounding, transposed through a per-wave patch (the patches / ring are dead),
+        // whole 128-byte rows out.  Padded position p = r * WP + c -> output pixel (h0 + r, c - 1); halo columns dropped.
+        OT* patch = reinterpret_cast<OT*>(smem) + wave * (16 * PROW);
+        char* obase = a.out + (((long long)frame * a.H + h0) * a.W) * a.out_ld * 2 + wn * 128;
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                f32x4 v = acc[i][j] * sc[i] + sf[i];
+                if (a.relu) { v[0] = relu_f(v[0]); v[1] = relu_f(v[1]); v[2] = relu_f(v[2]); v[3] = relu_f(v[3]); }
+                Vec4<DT>::store(reinterpret_cast<char*>(patch + frow * PROW + i * 16 + fg * 4), v);
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int row = it * 8 + rr;
+                const int p = (wm * MT + j) * 16 + row;
+                const int r = (int)(((float)p + 0.5f) * a.inv_wp), c = p - r * WP;
+                const u32x4 o = *reinterpret_cast<const u32x4*>(patch + row * PROW + cc);
+                if (r < a.R && c >= 1 && c <= a.W && h0 + r < a.H)
+                    __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(obase + (long long)(r * a.W + c - 1) * a.out_ld * 2 + cc * 2));
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        return;
+    }
+
+    // ---- fused `c` conv.  The band's b output (BN + ReLU, rounded once) becomes the B operand of a 1x1x1 convolution without
+    // leaving the CU: T[slab = wn][position p][64 channels] in LDS, swizzled like the patches (halo columns hold garbage that
+    // only feeds dropped outputs).  The c weights go global -> registers (16 bytes per lane = one A fragment, a K-step ahead):
+    // no ring, no barrier - every wave runs its 64 output channels x 112 positions on its own, Cout2 / BN passes.
+    constexpr int MPAD = WM * MT * 16;
+    char* T = reinterpret_cast<char*>(smem);
 #pragma unroll
     for (int j = 0; j < MT; ++j) {
+        const int p = (wm * MT + j) * 16 + frow;
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
             f32x4 v = acc[i][j] * sc[i] + sf[i];
             if (a.relu) { v[0] = relu_f(v[0]); v[1] = relu_f(v[1]); v[2] = relu_f(v[2]); v[3] = relu_f(v[3]); }
-            Vec4<DT>::store(reinterpret_cast<char*>(patch + frow * PROW + i * 16 + fg * 4), v);
+            const int chunk = i * 2 + (fg >> 1);
+            Vec4<DT>::store(T + (wn * MPAD + p) * 128 + ((chunk ^ (p & 7)) << 4) + (fg & 1) * 8, v);
         }
-        __builtin_amdgcn_wave_barrier();
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                      // T complete
+    constexpr int SROW = 64 + 4;                       // fp32 staging row stride (floats)
+    float* stg = reinterpret_cast<float*>(T + WN * MPAD * 128) + wave * (16 * SROW);
+    const long long pix0 = ((long long)frame * a.H + h0) * a.W;
+    const int passes = a.Cout2 / BN;
+    const int Cmid = BN;                               // K of the c conv = the b conv's output channels
+    for (int pass = 0; pass < passes; ++pass) {
+        const int ch0 = pass * BN + wn * 64;
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int row = it * 8 + rr;
-            const int p = (wm * MT + j) * 16 + row;
-            const int r = (int)(((float)p + 0.5f) * a.inv_wp), c = p - r * WP;
-            const u32x4 o = *reinterpret_cast<const u32x4*>(patch + row * PROW + cc);
-            if (r < a.R && c >= 1 && c <= a.W && h0 + r < a.H)
-                __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(obase + (long long)(r * a.W + c - 1) * a.out_ld * 2 + cc * 2));
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // A fragments (c weights) straight from global memory, two k-halves ahead of their MFMAs (3 register sets)
+        uint4 an[3][NT];
+        auto load_a = [&](uint4 (&dst)[NT], int h) {            // half-step h = (K-step h >> 1, k-half h & 1)
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+                dst[i] = *reinterpret_cast<const uint4*>(a.w2 + ((long long)(ch0 + i * 16 + frow) * Cmid + h * 32 + fg * 8) * 2);
+        };
+        load_a(an[0], 0);
+        load_a(an[1], 1);
+#pragma unroll
+        for (int h = 0; h < 2 * WN; ++h) {
+            if (h + 2 < 2 * WN) load_a(an[(h + 2) % 3], h + 2);
+            uint4 bf[MT];
+            const char* xsb = T + ((h >> 1) * MPAD + wm * MT * 16 + frow) * 128 + (((((h & 1) << 2) + fg) ^ (frow & 7)) << 4);
+#pragma unroll
+            for (int j = 0; j < MT; ++j) bf[j] = *reinterpret_cast<const uint4*>(xsb + j * (16 * 128));
+#pragma unroll
+            for (int t = 0; t < NTH; ++t) Mma<DT>::run(an[h % 3][t / MT], bf[t % MT], acc[t / MT][t % MT]);
         }
-        __builtin_amdgcn_wave_barrier();
+        // epilogue of the pass: BN in registers -> fp32 staging rows -> (+ residual) -> ReLU -> the one rounding -> 16-byte stores
+        f32x4 sc2[NT], sf2[NT];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            sc2[i] = *reinterpret_cast<const f32x4*>(a.scale2 + ch0 + i * 16 + fg * 4);
+            sf2[i] = *reinterpret_cast<const f32x4*>(a.shift2 + ch0 + i * 16 + fg * 4);
+        }
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+                *reinterpret_cast<f32x4*>(stg + frow * SROW + i * 16 + fg * 4) = acc[i][j] * sc2[i] + sf2[i];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int row = it * 8 + rr;
+                const int p = (wm * MT + j) * 16 + row;
+                const int r = (int)(((float)p + 0.5f) * a.inv_wp), c = p - r * WP;
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(stg + row * SROW + cc);
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(stg + row * SROW + cc + 4);
+                if (r < a.R && c >= 1 && c <= a.W && h0 + r < a.H) {
+                    const long long pix = pix0 + r * a.W + c - 1;
+                    float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                    if (a.res) {
+                        const uint4 rraw = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.res + (pix * a.Cout2 + ch0 + cc) * 2)));
+                        const OT* re = reinterpret_cast<const OT*>(&rraw);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += E::to_f32(re[e]);
+                    }
+                    uint4 o;
+                    OT* oe = reinterpret_cast<OT*>(&o);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) oe[e] = E::from_f32(a.relu2 ? relu_f(v[e]) : v[e]);
+                    __builtin_nontemporal_store(__builtin_bit_cast(u32x4, o), reinterpret_cast<u32x4*>(a.out + (pix * a.out_ld + ch0 + cc) * 2));
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
     }
 }
 
-template <int DT, int WN, int WM>
+template <int DT, int WN, int WM, bool FUSEC>
 static int launch133g(const C133GArgs& a, hipStream_t stream) {
-    const int lds = 2 * a.prows * 128 + 2 * WN * 64 * 128;
-    AF_SET_MAX_LDS((&conv133g_kernel<DT, WN, WM>), 160 * 1024, "conv133g");
-    hipLaunchKernelGGL((conv133g_kernel<DT, WN, WM>), dim3(a.frames * a.upf), dim3(512), lds, stream, a);
+    int lds = 2 * a.prows * 128 + 2 * WN * 64 * 128;
+    const int lds_c = WN * (WM * 7 * 16) * 128 + 8 * 16 * (64 + 4) * 4;       // T + the per-wave fp32 staging rows
+    if (FUSEC && lds_c > lds) lds = lds_c;
+    if (lds > 160 * 1024) return set_error(AF_ERR_ARG, "conv133g: %d bytes of LDS needed", lds);
+    AF_SET_MAX_LDS((&conv133g_kernel<DT, WN, WM, FUSEC>), 160 * 1024, "conv133g");
+    hipLaunchKernelGGL((conv133g_kernel<DT, WN, WM, FUSEC>), dim3(a.frames * a.upf), dim3(512), lds, stream, a);
     AF_CHECK_LAUNCH("conv133g_kernel");
     return AF_OK;
 }
@@ -250,17 +351,46 @@ bool conv133g_applies(const af_conv_desc* d, const void* residual, int out_ld) {
     return !residual && (out_ld == 0 || out_ld % 8 == 0) && conv133g_rows(d) != 0;
 }
 
-int conv133g_run(const af_conv_desc* d, const void* in, const void* w_packed, const float* scale, const float* shift,
-                 void* out, int out_ld, hipStream_t stream) {
-    C133GArgs a;
-    a.in = (const char*)in; a.w = (const char*)w_packed; a.scale = scale; a.shift = shift; a.out = (char*)out;
+static void fill133g(C133GArgs& a, const af_conv_desc* d, const void* in, const void* w_packed, const float* scale,
+                     const float* shift) {
+    a.in = (const char*)in; a.w = (const char*)w_packed; a.scale = scale; a.shift = shift;
     a.H = d->h; a.W = d->w; a.Cin = d->cin; a.Cout = d->cout; a.frames = d->n * d->t;
     a.R = conv133g_rows(d); a.upf = (d->h + a.R - 1) / a.R; a.WP = d->w + 2;
     a.prows = ((a.R + 2) * a.WP + 1 + 7) & ~7;
-    a.kslabs = d->cin / 64; a.relu = d->relu; a.out_ld = out_ld ? out_ld : d->cout;
+    a.kslabs = d->cin / 64; a.relu = d->relu;
     a.inv_wp = 1.0f / (float)a.WP;
-    if (d->cout == 256) return d->dtype == AF_BF16 ? launch133g<AF_BF16, 4, 2>(a, stream) : launch133g<AF_F16, 4, 2>(a, stream);
-    return d->dtype == AF_BF16 ? launch133g<AF_BF16, 2, 4>(a, stream) : launch133g<AF_F16, 2, 4>(a, stream);
+    a.w2 = nullptr; a.scale2 = a.shift2 = nullptr; a.res = nullptr; a.Cout2 = 0; a.relu2 = 0;
+}
+
+// b (1x3x3) + c (1x1x1, + residual, + ReLU) of a bottleneck as one launch: true iff `db` takes the frame-resident path and
+// `dc` is a plain 1x1x1 convolution over db's output whose channel count is a multiple of db's
+bool conv133g_fused_applies(const af_conv_desc* db, const af_conv_desc* dc, int out_ld) {
+    if (!db || !dc || !conv133g_applies(db, nullptr, 0)) return false;
+    if (dc->dtype != db->dtype || dc->tpool || dc->kt != 1 || dc->kh != 1 || dc->kw != 1) return false;
+    if (dc->st != 1 || dc->sh != 1 || dc->sw != 1 || dc->pt || dc->ph || dc->pw) return false;
+    if (dc->n != db->n || dc->t != db->to || dc->h != db->ho || dc->w != db->wo || dc->cin != db->cout) return false;
+    if (dc->cout % db->cout != 0) return false;
+    return out_ld == 0 || (out_ld >= dc->cout && out_ld % 8 == 0);
+}
+
+int conv133g_fused_run(const af_conv_desc* db, const void* in, const void* wb, const float* scale_b, const float* shift_b,
+                       const af_conv_desc* dc, const void* wc, const float* scale_c, const float* shift_c, const void* residual,
+                       void* out, int out_ld, hipStream_t stream) {
+    C133GArgs a;
+    fill133g(a, db, in, wb, scale_b, shift_b);
+    a.out = (char*)out; a.out_ld = out_ld ? out_ld : dc->cout;
+    a.w2 = (const char*)wc; a.scale2 = scale_c; a.shift2 = shift_c; a.res = (const char*)residual; a.Cout2 = dc->cout; a.relu2 = dc->relu;
+    if (db->cout == 256) return db->dtype == AF_BF16 ? launch133g<AF_BF16, 4, 2, true>(a, stream) : launch133g<AF_F16, 4, 2, true>(a, stream);
+    return db->dtype == AF_BF16 ? launch133g<AF_BF16, 2, 4, true>(a, stream) : launch133g<AF_F16, 2, 4, true>(a, stream);
+}
+
+int conv133g_run(const af_conv_desc* d, const void* in, const void* w_packed, const float* scale, const float* shift,
+                 void* out, int out_ld, hipStream_t stream) {
+    C133GArgs a;
+    fill133g(a, d, in, w_packed, scale, shift);
+    a.out = (char*)out; a.out_ld = out_ld ? out_ld : d->cout;
+    if (d->cout == 256) return d->dtype == AF_BF16 ? launch133g<AF_BF16, 4, 2, false>(a, stream) : launch133g<AF_F16, 4, 2, false>(a, stream);
+    return d->dtype == AF_BF16 ? launch133g<AF_BF16, 2, 4, false>(a, stream) : launch133g<AF_F16, 2, 4, false>(a, stream);
 }
 
 }  // namespace af

@@ -7,6 +7,7 @@ pool -> s3 -> ... -> head, with every Conv3d+BatchNorm3d(+add)(+ReLU)(+pool) gro
 launch.  PyTorch is used only to own device memory and the stream.
 """
 import ctypes as C
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -19,10 +20,10 @@ _TORCH_DTYPE = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float
 
 # op tags (echoed by the timed runner; used by bench.py to attribute device time to kernel classes)
 TAG_PACK, TAG_STEM, TAG_POOL, TAG_HEAD = 0, 1, 2, 3
-TAG_CONV_1x1x1, TAG_CONV_Tx1x1, TAG_CONV_1x3x3, TAG_CONV_OTHER = 10, 11, 12, 13
+TAG_CONV_1x1x1, TAG_CONV_Tx1x1, TAG_CONV_1x3x3, TAG_CONV_OTHER, TAG_CONV_BC = 10, 11, 12, 13, 14
 TAG_NAMES = {TAG_PACK: "input_pack", TAG_STEM: "stem_5x7x7", TAG_POOL: "maxpool", TAG_HEAD: "head",
              TAG_CONV_1x1x1: "conv_1x1x1", TAG_CONV_Tx1x1: "conv_3x1x1", TAG_CONV_1x3x3: "conv_1x3x3",
-             TAG_CONV_OTHER: "conv_other"}
+             TAG_CONV_OTHER: "conv_other", TAG_CONV_BC: "conv_1x3x3+1x1x1_fused"}
 TAG_NAMES[TAG_STEM] = "stem"
 
 
@@ -145,11 +146,32 @@ class PackedWeights:
         torch.cuda.current_stream(device).synchronize()      # sources may be freed by the caller
 
 
+def _fill_conv_desc(cd, batch, code, cv: ConvSpec, din, dout, relu):
+    cd.n, (cd.t, cd.h, cd.w), cd.cin, cd.cout = batch, din, cv.cin, cv.cout
+    cd.kt, cd.kh, cd.kw = cv.kernel
+    cd.st, cd.sh, cd.sw = cv.stride
+    cd.pt, cd.ph, cd.pw = cv.pad
+    cd.to, cd.ho, cd.wo = dout
+    cd.relu, cd.dtype = int(relu), code
+
+
 class _Plan:
     """Accumulates plan entries (dicts) and the element count every named activation buffer must hold."""
 
-    def __init__(self, batch):
-        self.batch, self.entries, self.sizes = batch, [], {}
+    def __init__(self, batch, code=None):
+        self.batch, self.entries, self.sizes, self.code = batch, [], {}, code
+
+    def bc_fusable(self, b: ConvSpec, c: ConvSpec, da, db, dc) -> bool:
+        """does the library run this bottleneck's b (1x3x3) and c (1x1x1 + residual) convs as one launch (af_conv3d_bc_bn_act)?
+        OFF unless AF_FUSE_BC=1: measured slower (B=16, bf16: s3 0.205 ms against 0.068 + 0.080 ms for the two launches, s4
+        0.134 against 0.056 + 0.070) - the b conv is MFMA-bound, the c conv with its residual an HBM stream, and inside one
+        workgroup the two phases run back to back on every CU at the same time instead of overlapping."""
+        if self.code is None or os.environ.get("AF_FUSE_BC") != "1":
+            return False
+        d1, d2 = _lib.ConvDesc(), _lib.ConvDesc()
+        _fill_conv_desc(d1, self.batch, self.code, b, da, db, True)
+        _fill_conv_desc(d2, self.batch, self.code, c, db, dc, True)
+        return bool(lib.af_conv_bc_fusable(C.byref(d1), C.byref(d2)))
 
     def need(self, buf, dims, width):
         self.sizes[buf] = max(self.sizes.get(buf, 0), self.batch * dims[0] * dims[1] * dims[2] * width)
@@ -175,6 +197,16 @@ class _Plan:
                 dbp = _pool_out(db, pb)
                 self.add(kind="conv", cv=blk.b, din=da, dout=db, src=a_buf, dst=b_buf, tpool=2); self.need(b_buf, dbp, blk.b.cout)
                 db = dbp
+            elif (pb is None and blk.branch1 is None and not (tpool_last and bi == nblk - 1) and
+                  self.bc_fusable(blk.b, blk.c, da, db, blk.c.out_dims(*db))):
+                # b + c + residual + ReLU in one launch: the b output of a frame stays in LDS (s3 / s4 at bench batch sizes)
+                dc = blk.c.out_dims(*db)
+                ld = last_ld if (bi == nblk - 1 and last_ld) else blk.c.cout
+                self.add(kind="bc", cv=blk.b, cv2=blk.c, din=da, dmid=db, dout=dc, src=a_buf, dst=nxt, res=cur, ld=ld)
+                self.need(nxt, dc, ld)
+                cur, nxt = nxt, cur
+                d, c = dc, blk.c.cout
+                continue
             else:
                 self.add(kind="conv", cv=blk.b, din=da, dout=db, src=a_buf, dst=b_buf); self.need(b_buf, db, blk.b.cout)
                 if pb is not None:       # odd sizes / other pool shapes: the pool as its own launch into the free a buffer
@@ -221,7 +253,7 @@ class Engine:
         self.code = _lib.DTYPE_CODES[self.dtype]
         T, H, W = dims or (spec.num_frames, spec.crop, spec.crop)
         self.in_dims = (T, H, W)
-        plan = _Plan(batch)
+        plan = _Plan(batch, self.code)
         if isinstance(spec, SlowFastSpec):
             self._plan_slowfast(plan, spec, T, H, W)
         elif isinstance(spec, FtcnTTSpec):
@@ -364,12 +396,7 @@ class Engine:
             self.op_macs.append(0)
 
         def fill_conv(cd, cv: ConvSpec, din, dout, relu):
-            cd.n, (cd.t, cd.h, cd.w), cd.cin, cd.cout = batch, din, cv.cin, cv.cout
-            cd.kt, cd.kh, cd.kw = cv.kernel
-            cd.st, cd.sh, cd.sw = cv.stride
-            cd.pt, cd.ph, cd.pw = cv.pad
-            cd.to, cd.ho, cd.wo = dout
-            cd.relu, cd.dtype = int(relu), self.code
+            _fill_conv_desc(cd, batch, self.code, cv, din, dout, relu)
 
         def fill_pool(pd, din, ch, kernel, stride, pad, dout):
             pd.n, (pd.t, pd.h, pd.w), pd.c = batch, din, ch
@@ -405,6 +432,19 @@ class Engine:
                 op.out_ld = e.get("ld", cv.cout)
                 self.op_names.append(cv.conv)
                 self.op_macs.append(batch * cv.macs(*e["din"]))
+            elif kind == "bc":
+                cvb, cvc = e["cv"], e["cv2"]
+                op.kind, op.tag = _lib.AF_OP_CONV_BC, TAG_CONV_BC
+                fill_conv(op.conv, cvb, e["din"], e["dmid"], True)
+                fill_conv(op.conv2, cvc, e["dmid"], e["dout"], True)      # final_bn: takes the block's add + ReLU
+                op.weight, op.scale, op.shift = (weights.w[cvb.conv].data_ptr(), weights.scale[cvb.conv].data_ptr(),
+                                                 weights.shift[cvb.conv].data_ptr())
+                op.weight2, op.scale2, op.shift2 = (weights.w[cvc.conv].data_ptr(), weights.scale[cvc.conv].data_ptr(),
+                                                    weights.shift[cvc.conv].data_ptr())
+                op.residual = self.buf[e["res"]].data_ptr()
+                op.out_ld = e.get("ld", cvc.cout)
+                self.op_names.append(cvb.conv + "+c")
+                self.op_macs.append(batch * (cvb.macs(*e["din"]) + cvc.macs(*e["dmid"])))
             elif kind == "dual":
                 cvc, cv1 = e["cv"], e["cv2"]
                 op.kind, op.tag = _lib.AF_OP_CONV_DUAL, _conv_tag(cvc)
@@ -624,6 +664,8 @@ class Engine:
         op = self.ops[op_index]
         if op.kind == _lib.AF_OP_STEM_POOL:
             shape = (op.conv.n, op.conv.to, (op.conv.ho - 1) // 2 + 1, (op.conv.wo - 1) // 2 + 1, op.conv.cout)
+        elif op.kind == _lib.AF_OP_CONV_BC:
+            shape = (op.conv2.n, op.conv2.to, op.conv2.ho, op.conv2.wo, op.out_ld or op.conv2.cout)
         elif op.kind in (_lib.AF_OP_STEM, _lib.AF_OP_CONV, _lib.AF_OP_CONV_DUAL, _lib.AF_OP_TSTEM):
             ld = op.out_ld or op.conv.cout
             q = 2 if op.conv.tpool == 2 else 1

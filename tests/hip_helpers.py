@@ -74,6 +74,42 @@ def conv_bn_act(x_ndhwc, w_oidhw, scale, shift, stride, pad, relu, dtype, residu
     return out
 
 
+def _pack_plain(w_oidhw, dtype):
+    L = lib()
+    code = L.DTYPE_CODES[dtype]
+    cout, cin, kt, kh, kw = w_oidhw.shape
+    wsrc = w_oidhw.float().cuda().contiguous()
+    nbytes = L.lib.af_packed_conv_weight_bytes(cout, cin, kt, kh, kw, code)
+    packed = torch.empty(nbytes // (4 if dtype == "f32" else 2), dtype=TORCH_DT[dtype], device="cuda")
+    L.check(L.lib.af_pack_conv_weight(_p(wsrc), cout, cin, kt, kh, kw, code, _p(packed), _stream()), "pack_conv_weight")
+    torch.cuda.current_stream().synchronize()
+    return packed
+
+
+def conv_bc(x_ndhwc, wb_oidhw, bn_b, wc_oidhw, bn_c, residual, dtype):
+    """relu(bn_c(conv1x1x1(relu(bn_b(conv1x3x3(x))))) + residual) as one af_conv3d_bc_bn_act launch; None if the library
+    does not fuse this pair (af_conv_bc_fusable)."""
+    L = lib()
+    code = L.DTYPE_CODES[dtype]
+    n, t, h, w, cin = x_ndhwc.shape
+    cmid, cout = wb_oidhw.shape[0], wc_oidhw.shape[0]
+    db, dc = L.ConvDesc(), L.ConvDesc()
+    db.n, db.t, db.h, db.w, db.cin, db.cout = n, t, h, w, cin, cmid
+    db.kt, db.kh, db.kw, db.st, db.sh, db.sw, db.pt, db.ph, db.pw = 1, 3, 3, 1, 1, 1, 0, 1, 1
+    db.to, db.ho, db.wo, db.relu, db.dtype = t, h, w, 1, code
+    dc.n, dc.t, dc.h, dc.w, dc.cin, dc.cout = n, t, h, w, cmid, cout
+    dc.kt = dc.kh = dc.kw = dc.st = dc.sh = dc.sw = 1
+    dc.to, dc.ho, dc.wo, dc.relu, dc.dtype = t, h, w, 1, code
+    if not L.lib.af_conv_bc_fusable(C.byref(db), C.byref(dc)):
+        return None
+    pb, pc = _pack_plain(wb_oidhw, dtype), _pack_plain(wc_oidhw, dtype)
+    out = torch.empty((n, t, h, w, cout), dtype=TORCH_DT[dtype], device="cuda")
+    L.check(L.lib.af_conv3d_bc_bn_act(C.byref(db), _p(x_ndhwc), _p(pb), _p(bn_b[0]), _p(bn_b[1]), C.byref(dc), _p(pc), _p(bn_c[0]),
+                                      _p(bn_c[1]), _p(residual), _p(out), 0, _stream()), "conv3d_bc_bn_act")
+    torch.cuda.current_stream().synchronize()
+    return out
+
+
 def _pack_scaled(w_oidhw, row_scale, dtype):
     L = lib()
     code = L.DTYPE_CODES[dtype]

@@ -422,3 +422,39 @@ def test_argument_errors_are_reported():
     with pytest.raises(L.AfError, match="multiple of"):
         hh.conv_bn_act(x, torch.zeros(64, 42, 1, 1, 1), torch.ones(64, device="cuda"), torch.zeros(64, device="cuda"),
                        (1, 1, 1), (0, 0, 0), False, "f32")
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+@pytest.mark.parametrize("name,cin,cmid,cout,dims,use_res", [
+    ("s4_like", 256, 256, 1024, (1, 192, 14, 14), True),          # whole 14x14 frames, 4 K slabs, 4 output passes
+    ("s3_like", 128, 128, 512, (2, 48, 28, 28), True),            # two bands of 14 rows per frame
+    ("ragged_no_res", 64, 128, 256, (1, 100, 27, 26), False),     # bands of 14 + 13 rows, no residual
+])
+def test_fused_b_c_vs_oracle(name, cin, cmid, cout, dims, use_res, dtype):
+    """af_conv3d_bc_bn_act: relu(bn_c(c(relu(bn_b(b(x))))) + residual) in one launch (the b output stays in LDS) against the
+    oracle's two conv_bn_act calls in fp64; the intermediate is rounded to the storage type on both sides."""
+    seed = 4000 + sum(map(ord, name))
+    lay = [("b.weight", (cmid, cin, 1, 3, 3), "float32"), ("c.weight", (cout, cmid, 1, 1, 1), "float32")]
+    for p_, ch in (("b_bn", cmid), ("c_bn", cout)):
+        lay += [(p_ + s_, (ch,), "float32") for s_ in (".weight", ".bias", ".running_mean", ".running_var")]
+    sd = synth.fill_layout(lay, seed)
+    tdt = hh.TORCH_DT[dtype]
+    x = synth.synthetic_tensor((dims[0], cin) + dims[1:], seed).to(tdt).float()
+    for k in ("b.weight", "c.weight"):
+        sd[k] = sd[k].to(tdt).float()
+    sd64 = {k: v.double() for k, v in sd.items()}
+    mid = oracle.conv_bn_act(x.double(), sd64["b.weight"], sd64, "b_bn", (1, 1, 1), (0, 1, 1), True)
+    mid = mid.to(tdt).double()                                  # the one rounding of the b output (LDS tile in the storage type)
+    want = oracle.conv_bn_act(mid, sd64["c.weight"], sd64, "c_bn", (1, 1, 1), (0, 0, 0), False)
+    res = None
+    if use_res:
+        res = synth.synthetic_tensor(tuple(want.shape), seed + 1).to(tdt).float()
+        want = want + res.double()
+    want = F.relu(want)
+    got = hh.conv_bc(hh.to_ndhwc(x, dtype), sd["b.weight"], hh.fold_bn(sd, "b_bn"), sd["c.weight"], hh.fold_bn(sd, "c_bn"),
+                     None if res is None else hh.to_ndhwc(res, dtype), dtype)
+    assert got is not None, "the library should fuse this pair"
+    got = hh.to_ncdhw(got).double()
+    tol = {"f16": 2e-3, "bf16": 1.6e-2}[dtype]                   # a b value on a rounding boundary may round the other way
+    err = (got - want).abs().max().item()
+    assert err <= tol * (want.abs().max().item() + 1e-9), "%s[%s] err %.3e" % (name, dtype, err)
