@@ -130,6 +130,23 @@ int af_stem_conv_bn_relu(const af_conv_desc* d, const void* stem_in, const void*
 int af_stem_conv_bn_relu_maxpool(const af_conv_desc* d, const void* stem_in, const void* w_packed,
                                  const float* scale, const float* shift, void* out, void* stream);
 
+/* The same fused stem on the K-PACKED input ("rgb3": 3 real channels per pixel, 6 bytes; rows of
+ * ((w + 8) * 6 rounded up to 16) bytes, frames / rows / left halo padded like the 4-channel layout): the 7 x 7 x 3 taps of a
+ * (dt) plane fill 5.25 MFMA K-blocks instead of 7 - the stem is MFMA-bound on exactly that padding (kt = 5: 27 blocks instead
+ * of 35).  af_stem_input_bytes_rgb3 includes the few rows of slack the last frame needs; the buffer is zero-filled once by
+ * the caller, af_pack_input_*_rgb3 write the interior (same arguments and arithmetic as af_pack_input_*); weights:
+ * af_pack_stem_weight_rgb3 -> af_packed_stem_weight_bytes_rgb3(kt, dtype) bytes.  16-bit dtypes, 64 output channels. */
+int64_t af_stem_input_bytes_rgb3(int n, int t, int h, int w, int dtype);
+int af_pack_input_f32_rgb3(const float* x, int n, int t, int h, int w,
+                           int64_t stride_n, int64_t stride_c, int64_t stride_t, int64_t stride_h, int64_t stride_w,
+                           int dtype, void* stem_in, void* stream);
+int af_pack_input_u8_rgb3(const uint8_t* clips, int n, int t, int h, int w,
+                          const float mean[3], const float std_[3], int dtype, void* stem_in, void* stream);
+int64_t af_packed_stem_weight_bytes_rgb3(int kt, int dtype);
+int af_pack_stem_weight_rgb3(const float* w_oidhw, int cout, int kt, int dtype, void* packed, void* stream);
+int af_stem_conv_bn_relu_maxpool_rgb3(const af_conv_desc* d, const void* stem_in, const void* w_packed,
+                                      const float* scale, const float* shift, void* out, void* stream);
+
 /* Conv3d(bias=False)+BN[+residual add][+ReLU] as one implicit-GEMM launch: the a/b/c convs of
  * BottleneckTransform (resnet_helper.py:267-325), the projection shortcut and the add+ReLU of
  * ResBlock (resnet_helper.py:411-444), FuseFastToSlow's conv_f2s+bn+relu (video_model_builder.py:121-143).
@@ -288,7 +305,9 @@ enum af_op_kind { AF_OP_STEM = 0, AF_OP_CONV = 1, AF_OP_MAXPOOL = 2, AF_OP_HEAD 
                   AF_OP_TSTEM = 10, AF_OP_TOKENS = 11, AF_OP_LAYERNORM = 12, AF_OP_ATTENTION = 13, AF_OP_GELU = 14,
                   /* b + c of a bottleneck in one launch: conv / weight / scale / shift = the b conv, conv2 / weight2 / scale2 /
                      shift2 = the c conv, residual, out, out_ld (af_conv3d_bc_bn_act) */
-                  AF_OP_CONV_BC = 15 };
+                  AF_OP_CONV_BC = 15,
+                  /* the K-packed stem path: same fields as PACK_F32 / PACK_U8 / STEM_POOL, rgb3 input layout */
+                  AF_OP_PACK3_F32 = 16, AF_OP_PACK3_U8 = 17, AF_OP_STEM3_POOL = 18 };
 
 typedef struct af_op {
     int32_t kind;                    /* af_op_kind */

@@ -58,6 +58,15 @@ static int run_one(const af_op& op, hipStream_t s) {
         case AF_OP_PACK_U8:
             return af_pack_input_u8((const uint8_t*)op.in, op.conv.n, op.conv.t, op.conv.h, op.conv.w, op.mean, op.std_,
                                     op.conv.dtype, op.out, s);
+        case AF_OP_STEM3_POOL:
+            return af_stem_conv_bn_relu_maxpool_rgb3(&op.conv, op.in, op.weight, op.scale, op.shift, op.out, s);
+        case AF_OP_PACK3_F32:
+            return af_pack_input_f32_rgb3((const float*)op.in, op.conv.n, op.conv.t, op.conv.h, op.conv.w, op.in_strides[0],
+                                          op.in_strides[1], op.in_strides[2], op.in_strides[3], op.in_strides[4],
+                                          op.conv.dtype, op.out, s);
+        case AF_OP_PACK3_U8:
+            return af_pack_input_u8_rgb3((const uint8_t*)op.in, op.conv.n, op.conv.t, op.conv.h, op.conv.w, op.mean, op.std_,
+                                         op.conv.dtype, op.out, s);
         case AF_OP_TSTEM:
             return af_tstem_conv_bn_pool_relu(&op.conv, op.in, op.weight, op.scale, op.shift, op.out, s);
         case AF_OP_TOKENS:       /* in = pooled, weight = cls token, scale = position embedding; pool.n = clips, pool.t = tokens, pool.c = dim */

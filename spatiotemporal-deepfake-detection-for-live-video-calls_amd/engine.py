@@ -96,6 +96,14 @@ class PackedWeights:
                 check(lib.af_pack_conv_weight(_ptr(w), cv.cout, cv.cin, kt, kh, kw, code, _ptr(packed), st),
                       "af_pack_conv_weight")
             self.w[cv.conv], self.scale[cv.conv], self.shift[cv.conv] = packed, scale, shift
+            if (cv.conv in stems and not isinstance(spec, (FtcnTTSpec, SlowFastSpec)) and dtype != "f32" and cv.cout == 64
+                    and (kh, kw) == (7, 7)):
+                # the K-packed image of the same stem weights for the fused 16-bit stem (3 real channels, af_stem3.hip)
+                nb3 = lib.af_packed_stem_weight_bytes_rgb3(kt, code)
+                p3 = torch.empty(nb3 // es, dtype=_TORCH_DTYPE[dtype], device=device)
+                check(lib.af_pack_stem_weight_rgb3(_ptr(w), cv.cout, kt, code, _ptr(p3), st), "af_pack_stem_weight_rgb3")
+                self.w3 = getattr(self, "w3", {})
+                self.w3[cv.conv] = p3
         # block 0 of every stage: last 1x1x1 + projection shortcut share one accumulator (af_conv3d_dual_bn_act):
         # both weights get their BN scale folded in (fp32, before the rounding), shifts are summed
         self.w_folded, self.shift_sum, self.ones = {}, {}, {}
@@ -270,8 +278,10 @@ class Engine:
         d2 = _pool_out(d, spec.stem_pool)
         fuse_stem_pool = (self.dtype != "f32" and d[2] <= 128 and spec.stem.cout == 64 and
                           _is_pool(spec.stem_pool, (1, 3, 3), (1, 2, 2), (0, 1, 1)))
+        self.rgb3 = bool(fuse_stem_pool and spec.stem.conv in getattr(self.weights, "w3", {}))
         if fuse_stem_pool:        # conv + BN + ReLU + max-pool in one launch; the conv output never reaches HBM
-            plan.add(kind="stem_pool", cv=spec.stem, din=(T, H, W), dout=d, src="IN", dst=cur); plan.need(cur, d2, spec.stem.cout)
+            plan.add(kind="stem3_pool" if self.rgb3 else "stem_pool", cv=spec.stem, din=(T, H, W), dout=d, src="IN", dst=cur)
+            plan.need(cur, d2, spec.stem.cout)
         else:
             plan.add(kind="stem", cv=spec.stem, din=(T, H, W), dout=d, src="IN", dst=cur); plan.need(cur, d, spec.stem.cout)
             plan.add(kind="pool", pool=spec.stem_pool, ch=spec.stem.cout, din=d, dout=d2, src=cur, dst=nxt)
@@ -371,8 +381,11 @@ class Engine:
         tdt = _TORCH_DTYPE[self.dtype]
         es = 4 if self.dtype == "f32" else 2
         self.buf = {k: torch.empty(max(v, 8), dtype=tdt, device=device) for k, v in plan.sizes.items()}
+        self.rgb3 = getattr(self, "rgb3", False)
+        self.k_pack_f32 = _lib.AF_OP_PACK3_F32 if self.rgb3 else _lib.AF_OP_PACK_F32
+        self.k_pack_u8 = _lib.AF_OP_PACK3_U8 if self.rgb3 else _lib.AF_OP_PACK_U8
         for name, dims, _ in self.inputs:                           # padded stem inputs: halos stay zero forever
-            nbytes = lib.af_stem_input_bytes(batch, dims[0], dims[1], dims[2], self.code)
+            nbytes = (lib.af_stem_input_bytes_rgb3 if self.rgb3 else lib.af_stem_input_bytes)(batch, dims[0], dims[1], dims[2], self.code)
             self.buf[name] = torch.zeros(nbytes // es, dtype=tdt, device=device)
         self.head_positions = self.head_dims[0] * self.head_dims[1] * self.head_dims[2]
         self.pooled = torch.empty((batch, self.head_positions, self.head_width), dtype=torch.float32, device=device)
@@ -389,7 +402,7 @@ class Engine:
         self.op_dst: List[Optional[str]] = [name for name, _, _ in self.inputs] + [e.get("dst") for e in plan.entries]
         for i, (name, dims, _) in enumerate(self.inputs):
             pk = self.ops[i]
-            pk.kind, pk.tag = _lib.AF_OP_PACK_F32, TAG_PACK
+            pk.kind, pk.tag = self.k_pack_f32, TAG_PACK
             pk.conv.n, (pk.conv.t, pk.conv.h, pk.conv.w), pk.conv.dtype = batch, dims, self.code
             pk.out = self.buf[name].data_ptr()
             self.op_names.append("input_pack" if n_pack == 1 else "input_pack_" + name)
@@ -416,16 +429,16 @@ class Engine:
             if kind == "tt_head":
                 self._materialise_tt_head(n_pack + k, e)
                 continue
-            if kind in ("stem", "stem_pool", "conv", "tstem"):
+            if kind in ("stem", "stem_pool", "stem3_pool", "conv", "tstem"):
                 cv: ConvSpec = e["cv"]
-                op.kind = {"stem": _lib.AF_OP_STEM, "stem_pool": _lib.AF_OP_STEM_POOL,
+                op.kind = {"stem": _lib.AF_OP_STEM, "stem_pool": _lib.AF_OP_STEM_POOL, "stem3_pool": _lib.AF_OP_STEM3_POOL,
                            "tstem": _lib.AF_OP_TSTEM}.get(kind, _lib.AF_OP_CONV)
                 op.tag = TAG_STEM if kind != "conv" else _conv_tag(cv)
                 # a, b, stems and laterals carry their own ReLU; c (final_bn) takes the block's add + ReLU; the
                 # projection shortcut has neither (resnet_helper.py:311-326, 438-444; video_model_builder.py:136-143)
                 fill_conv(op.conv, cv, e["din"], e["dout"], cv.relu or cv.final_bn)
                 op.conv.tpool = int(e.get("tpool") or 0)
-                op.weight = weights.w[cv.conv].data_ptr()
+                op.weight = (weights.w3 if kind == "stem3_pool" else weights.w)[cv.conv].data_ptr()
                 op.scale = weights.scale[cv.conv].data_ptr()
                 op.shift = weights.shift[cv.conv].data_ptr()
                 op.residual = self.buf[e["res"]].data_ptr() if e.get("res") else None
@@ -608,7 +621,7 @@ class Engine:
         if x.dtype != torch.float32 or not x.is_cuda:
             raise ValueError("inputs must be fp32 HIP tensors")
         pk = self.ops[i]
-        pk.kind = _lib.AF_OP_PACK_F32
+        pk.kind = self.k_pack_f32
         pk.in_ = x.data_ptr()
         st = list(x.stride())
         st[2] *= tstride
@@ -638,7 +651,7 @@ class Engine:
         if (B, T, H, W, Cc) != (self.batch,) + self.in_dims + (3,) or not clips.is_contiguous():
             raise ValueError("expected contiguous uint8 clips (%d,%d,%d,%d,3)" % ((self.batch,) + self.in_dims))
         pk = self.ops[0]
-        pk.kind = _lib.AF_OP_PACK_U8
+        pk.kind = self.k_pack_u8
         pk.in_ = clips.data_ptr()
         for i in range(3):
             pk.mean[i], pk.std_[i] = float(mean[i]), float(std[i])
@@ -662,7 +675,7 @@ class Engine:
         """Output of op ``op_index`` as an (N,T,H,W,C) view of its buffer (valid until overwritten; ops that write
         into a wider, concatenated row return the full-width rows)."""
         op = self.ops[op_index]
-        if op.kind == _lib.AF_OP_STEM_POOL:
+        if op.kind in (_lib.AF_OP_STEM_POOL, _lib.AF_OP_STEM3_POOL):
             shape = (op.conv.n, op.conv.to, (op.conv.ho - 1) // 2 + 1, (op.conv.wo - 1) // 2 + 1, op.conv.cout)
         elif op.kind == _lib.AF_OP_CONV_BC:
             shape = (op.conv2.n, op.conv2.to, op.conv2.ho, op.conv2.wo, op.out_ld or op.conv2.cout)

@@ -216,6 +216,39 @@ def stem_conv_pool(stem_in, dims, w_oidhw, scale, shift, dtype):
     return out
 
 
+def stem3_conv_pool(x_ncdhw_dev, w_oidhw, scale, shift, dtype, u8=None, mean=None, std=None):
+    """the K-packed fused stem (rgb3 input layout): pack (fp32 strided source, or uint8 clips) + conv + BN + ReLU + max-pool"""
+    L = lib()
+    code = L.DTYPE_CODES[dtype]
+    if u8 is None:
+        n, _, t, h, w = x_ncdhw_dev.shape
+    else:
+        n, t, h, w, _ = u8.shape
+    nbytes = L.lib.af_stem_input_bytes_rgb3(n, t, h, w, code)
+    buf = torch.zeros(nbytes // 2, dtype=TORCH_DT[dtype], device="cuda")
+    if u8 is None:
+        s = x_ncdhw_dev.stride()
+        L.check(L.lib.af_pack_input_f32_rgb3(_p(x_ncdhw_dev), n, t, h, w, s[0], s[1], s[2], s[3], s[4], code, _p(buf), _stream()),
+                "pack_input_f32_rgb3")
+    else:
+        m, sd_ = (C.c_float * 3)(*mean), (C.c_float * 3)(*std)
+        L.check(L.lib.af_pack_input_u8_rgb3(_p(u8), n, t, h, w, m, sd_, code, _p(buf), _stream()), "pack_input_u8_rgb3")
+    cout, _, kt, kh, kw = w_oidhw.shape
+    d = L.ConvDesc()
+    d.n, d.t, d.h, d.w, d.cin, d.cout = n, t, h, w, 3, cout
+    d.kt, d.kh, d.kw, d.st, d.sh, d.sw, d.pt, d.ph, d.pw = kt, kh, kw, 1, 2, 2, kt // 2, 3, 3
+    d.to, d.ho, d.wo = t, (h + 6 - 7) // 2 + 1, (w + 6 - 7) // 2 + 1
+    d.relu, d.dtype = 1, code
+    wsrc = w_oidhw.float().cuda().contiguous()
+    packed = torch.empty(L.lib.af_packed_stem_weight_bytes_rgb3(kt, code) // 2, dtype=TORCH_DT[dtype], device="cuda")
+    L.check(L.lib.af_pack_stem_weight_rgb3(_p(wsrc), cout, kt, code, _p(packed), _stream()), "pack_stem_weight_rgb3")
+    out = torch.empty((n, d.to, (d.ho - 1) // 2 + 1, (d.wo - 1) // 2 + 1, cout), dtype=TORCH_DT[dtype], device="cuda")
+    L.check(L.lib.af_stem_conv_bn_relu_maxpool_rgb3(C.byref(d), _p(buf), _p(packed), _p(scale), _p(shift), _p(out), _stream()),
+            "stem_conv_bn_relu_maxpool_rgb3")
+    torch.cuda.current_stream().synchronize()
+    return out
+
+
 def maxpool(x_ndhwc, kernel, stride, pad, dtype):
     L = lib()
     n, t, h, w, c = x_ndhwc.shape

@@ -59,7 +59,9 @@ def hip_stem(x_ncdhw, sd, p, dtype, fused=None):
     sin = hh.pack_input_f32(xd, dtype)
     scale, shift = hh.fold_bn(sd, p + ".bn")
     if fused is None:
-        fused = dtype != "f32"                  # what the engine does: one launch for conv + BN + ReLU + pool
+        fused = "rgb3" if dtype != "f32" else False      # what the engine does: one K-packed launch for conv + BN + ReLU + pool
+    if fused == "rgb3":
+        return hh.to_ncdhw(hh.stem3_conv_pool(xd, sd[p + ".conv.weight"], scale, shift, dtype))
     if fused:
         return hh.to_ncdhw(hh.stem_conv_pool(sin, (n, t, h, w), sd[p + ".conv.weight"], scale, shift, dtype))
     y = hh.stem_conv(sin, (n, t, h, w), sd[p + ".conv.weight"], scale, shift, dtype)
@@ -116,6 +118,19 @@ def test_stem_unfused_path_and_odd_sizes(golden_f3, dtype):
         x = synth.synthetic_tensor(shape, 92 + shape[3])
         want = oracle.stem(x, sd, "s")
         _close(hip_stem(x, sd, "s", dtype, fused=True), want, dtype, "stem %s" % (shape,), scale=3.0)
+        _close(hip_stem(x, sd, "s", dtype, fused="rgb3"), want, dtype, "stem rgb3 %s" % (shape,), scale=3.0)
+    # the K-packed stem with kt = 3 and kt = 1 (11 / 16 and 21 / 24 fragments in the last K-block), odd width, and its uint8 prologue
+    x = synth.synthetic_tensor((1, 3, 2, 18, 230), 99)          # 8 column tiles: no free wave, pooling by the whole workgroup
+    _close(hip_stem(x, sd, "s", dtype, fused="rgb3"), oracle.stem(x, sd, "s"), dtype, "stem rgb3 wide", scale=3.0)
+    for kt, shape in ((3, (1, 3, 3, 20, 37)), (1, (1, 3, 2, 33, 18))):
+        lay_k = [("s.conv.weight", (64, 3, kt, 7, 7), "float32")] + lay[1:]
+        sdk = synth.fill_layout(lay_k, 93 + kt)
+        x = synth.synthetic_tensor(shape, 95 + kt)
+        _close(hip_stem(x, sdk, "s", dtype, fused="rgb3"), oracle.stem(x, sdk, "s"), dtype, "stem rgb3 kt=%d" % kt, scale=3.0)
+    u8 = synth.synthetic_clips_u8(1, seed=7, kind="smooth", num_frames=3, size=40).cuda()
+    mean, std = synth.pixel_mean_std_f32()
+    got = hh.to_ncdhw(hh.stem3_conv_pool(None, sd["s.conv.weight"], *hh.fold_bn(sd, "s.bn"), dtype, u8=u8, mean=mean.tolist(), std=std.tolist()))
+    _close(got, oracle.stem(synth.normalize_like_callers(u8.cpu()), sd, "s"), dtype, "stem rgb3 u8", scale=3.0)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
