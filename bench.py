@@ -361,6 +361,74 @@ def bench_dualrun_rgb(args, rank, world, dev):
         dist.destroy_process_group()
 
 
+def bench_stream(args, rank, world, dev):
+    """BASELINE config[4] stand-in: the af_realtime.py loop around the hot path on a synthetic 1080p30 stream with ONE
+    tracked face.  The detectors / tracker (YuNet, ByteTrack: cv2, lap, cython_bbox - absent offline) are out of scope, so the
+    stream is pre-synthesised as what they hand over: per window 32 tracked crops (~420 px) + 5 / 68-point landmarks.  A window of
+    clip_size = 32 frames closes every stride = 30 frames (test/app_realtime.py:153), i.e. once per second at 30 fps; at that
+    moment it is "enqueued" and goes through aligner (FasterCropAlignXRay, device output) -> uint8 prologue -> AltFreezing forward
+    (B = 1) -> sigmoid -> host.  Reported: enqueue -> score latency p50 / p95 under real-time pacing (the GPU idles between windows,
+    as in a live call), and the sustained rate of the same pipeline back to back (= how many 30-fps tracks one GPU keeps up with)."""
+    import numpy as np
+    from af_mi355x import aligner, synth
+    from af_mi355x.classifier import Classifier
+    sd = synth.synthetic_state_dict(seed=0)
+    clf = Classifier(precision=args.dtype)
+    clf.network.load_state_dict(sd)
+    clf = clf.to(dev).eval()
+    al = aligner.FasterCropAlignXRay(224, device=dev)
+    windows = [aligner.synthetic_clip(32, seed=2026 + 100 * rank + i) for i in range(4)]
+    fps, stride = 30.0, 30
+    period = stride / fps
+
+    def process(k):
+        infos, crops = windows[k % len(windows)]
+        _, clip = al(infos, crops, device_output=True)                   # (32, 224, 224, 3) uint8 in HBM
+        return clf.network.infer_scores(clip.unsqueeze(0))               # numpy (1,): synchronises
+
+    with torch.inference_mode():
+        for k in range(max(args.warmup, 2)):
+            process(k)
+        torch.cuda.synchronize(dev)
+        lat = []
+        t0 = time.perf_counter()
+        for k in range(args.steps):                                      # real-time pacing: window k closes at t0 + (k + 1) * period
+            due = t0 + (k + 1) * period * args.pace
+            while True:
+                now = time.perf_counter()
+                if now >= due:
+                    break
+                time.sleep(min(0.005, due - now))
+            ts = time.perf_counter()
+            s = process(k)
+            lat.append(1e3 * (time.perf_counter() - ts))
+        n_sus = 50
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for k in range(n_sus):
+            s = process(k)
+        sustained = n_sus / (time.perf_counter() - t1)
+    lat = np.array(lat)
+    line = {"metric": "enqueue->score latency, 1080p30 stream stand-in (1 track, 32-frame windows every 30 frames)",
+            "value": round(float(np.percentile(lat, 50)), 3), "unit": "ms (p50)", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(float(lat.mean()), 3), "higher_is_better": False, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+            "data": "synthetic",
+            "config": {"workload": "BASELINE config[4] stand-in: per window 32 tracked crops (~420 px) -> FasterCropAlignXRay (HIP warp) -> "
+                                   "uint8 prologue -> AltFreezing i3d_ori forward B=1 -> sigmoid -> host; windows paced at %.2f s (x%.2f)"
+                                   % (period, args.pace), "clip_size": 32, "stride_frames": stride, "fps": fps},
+            "latency_ms": {"p50": round(float(np.percentile(lat, 50)), 3), "p95": round(float(np.percentile(lat, 95)), 3),
+                           "max": round(float(lat.max()), 3), "windows": int(lat.size)},
+            "sustained_clips_per_s": round(sustained, 2),
+            "tracks_at_30fps_per_gpu": round(sustained * period, 1),
+            "last_score": float(s[0]),
+            "not_measured": "face detection / tracking / landmarks on the 1080p frames (cv2, MediaPipe, lap absent offline)"}
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def bench_aligner(args, rank, world, dev):
     """SURVEY 8f rank 5 on its own: FasterCropAlignXRay's warps for `--batch` clips of 32 tracked crops (~420x420) -> 224x224
     per GPU; value = clips/s with the crops and the fitted transforms already resident (the warp launches only); the
@@ -549,9 +617,10 @@ def main():
     ap.add_argument("--batch", type=int, default=16, help="clips per GPU")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--cpu-clips", type=int, default=4, help="clips in the CPU baseline sample (0 = skip)")
-    ap.add_argument("--model", default="i3d", choices=["i3d", "slowfast", "ftcn_tt", "dualrun", "dualrun_rgb", "aligner", "conv3x3x3"],
+    ap.add_argument("--model", default="i3d", choices=["i3d", "slowfast", "ftcn_tt", "dualrun", "dualrun_rgb", "aligner", "conv3x3x3", "stream"],
                     help="i3d = the i3d_ori plugin (BASELINE metric); slowfast = the two-pathway SlowFast-R50, ftcn_tt = the "
                          "reference's second plugin (next rows of SURVEY 8f)")
+    ap.add_argument("--pace", type=float, default=1.0, help="--model stream: multiplier on the real-time window period (1.0 = 30 fps)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-parity-mode", action="store_true", help="skip the f16 (tolerance-meeting) leg next to a bf16 headline")
     ap.add_argument("--layers-json", default=None, help="write per-layer device times / rates to this file")
@@ -579,6 +648,8 @@ def main():
         return bench_dualrun(args, rank, world, dev)
     if args.model == "dualrun_rgb":
         return bench_dualrun_rgb(args, rank, world, dev)
+    if args.model == "stream":
+        return bench_stream(args, rank, world, dev)
     if args.model == "aligner":
         return bench_aligner(args, rank, world, dev)
     if args.model == "conv3x3x3":
