@@ -679,11 +679,11 @@ def main():
     else:
         sd = synth.synthetic_state_dict(seed=0)
 
-        def make_classifier(dtype):
-            c = Classifier(precision=dtype)
+        def make_classifier(dtype, streams=None):
+            c = Classifier(precision=dtype, streams=streams)
             c.network.load_state_dict(sd)
             return c.to(dev).eval()
-        clf = make_classifier(args.dtype)
+        clf = make_classifier(args.dtype, 1)             # the headline is the single-stream engine (what the roofline measures)
         net = clf.network
     u8 = synth.synthetic_clips_u8(B, seed=2026 + rank, kind="uniform")
     x = synth.normalize_like_callers(u8.to(dev))                       # (B,3,32,224,224) fp32, channels-last strides
@@ -744,6 +744,23 @@ def main():
             line["max_abs_logit_err_vs_cpu_fp32"] = err
             line["logit_tolerance"] = 1e-3
             line["meets_logit_tolerance"] = bool(err <= 1e-3)
+            if args.model == "i3d" and not args.no_parity_mode:
+                # opt-in execution mode of the same forward: the batch as two half-batches on two HIP streams (two engines)
+                clf2 = make_classifier(args.dtype, 2)
+                with torch.inference_mode():
+                    for _ in range(args.warmup):
+                        y2 = clf2(x)["final_output"]
+                    torch.cuda.synchronize(dev)
+                    t0 = time.perf_counter()
+                    for _ in range(args.steps):
+                        y2 = clf2(x)["final_output"]
+                    torch.cuda.synchronize(dev)
+                    dt2 = time.perf_counter() - t0
+                line["two_stream_mode"] = {"streams": 2, "value": round(B * args.steps / dt2, 2), "unit": "clips/s",
+                                           "ms_per_step": round(1e3 * dt2 / args.steps, 4),
+                                           "max_abs_logit_err_vs_cpu_fp32": float((y2[:n].float().cpu() - ref).abs().max()),
+                                           "note": "Classifier(streams=2) / AF_MI355X_STREAMS=2: off by default"}
+                del clf2
             if args.dtype == "bf16" and not args.no_parity_mode:
                 # bf16 (8 significant bits) does not reliably meet the 1e-3 logit tolerance; fp16 - the reference's own
                 # deployment precision (torch.amp.autocast, test/af_realtime.py:70,84) - does, at the same speed: the

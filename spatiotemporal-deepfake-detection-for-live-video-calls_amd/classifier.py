@@ -128,7 +128,7 @@ class _HipNetwork(nn.Module):
             return "bf16" if torch.get_autocast_dtype("cuda") == torch.bfloat16 else "f16"
         return "f32"
 
-    def _engine(self, dtype: str, batch: int, dims, device):
+    def _engine(self, dtype: str, batch: int, dims, device, slot: int = 0):
         from .engine import Engine, PackedWeights            # imports libafhip.so: fails loudly if absent
         sig = self._signature()
         cached = self._packed.get(dtype)
@@ -137,7 +137,7 @@ class _HipNetwork(nn.Module):
             self._packed[dtype] = (sig, PackedWeights(self.spec, state, dtype, device))
             for k in [k for k in self._engines if k[0] == dtype]:
                 del self._engines[k]
-        key = (dtype, batch, tuple(dims))
+        key = (dtype, batch, tuple(dims)) if slot == 0 else (dtype, batch, tuple(dims), slot)
         if key in self._engines:
             self._engines.move_to_end(key)
         else:
@@ -174,11 +174,44 @@ class _HipNetwork(nn.Module):
 class I3D8x8(_HipNetwork):
     """The plugin's network module (``module_to_build`` of the reference Classifier)."""
 
-    def __init__(self, clip_size: int = 32, imsize: int = 224, precision: str = "auto", crop_size: int = 224) -> None:
+    def __init__(self, clip_size: int = 32, imsize: int = 224, precision: str = "auto", crop_size: int = 224,
+                 streams: Optional[int] = None) -> None:
         # the head pool is sized from DATA.CROP_SIZE=224 (defaults.py:277), not from imsize (SURVEY App. B);
         # crop_size is only changed by tests that run a shrunken network
         super().__init__(i3d_r50_spec(num_frames=clip_size, crop=crop_size), precision)
         self.clip_size, self.imsize = clip_size, imsize
+        # streams = 2: a batch of >= split_min_batch clips runs as two half-batches on two HIP streams (two engines).  The forward
+        # alternates between MFMA-bound and HBM-bound launches and between full and 77 %-full rounds of tiles; the launches of
+        # two independent half-batches fill some of each other's idle time (measured: B=16 +3 %, B=32 +4.6 % - DESIGN.md 7).
+        # Off by default (1): opt in with the argument or AF_MI355X_STREAMS=2.
+        self.streams = int(streams if streams is not None else os.environ.get("AF_MI355X_STREAMS", "1"))
+        self.split_min_batch = 16
+        self._side = {}
+
+    def _run(self, B, dims, dev, runner):
+        """runner(engine, lo, hi) -> (logits, pooled) for clips [lo, hi).  Returns (an engine of the run, logits, pooled, scores)."""
+        dtype = self._select_dtype()
+        ns = self.streams if (self.streams > 1 and B >= self.split_min_batch) else 1
+        if ns == 1:
+            eng = self._engine(dtype, B, dims, dev)
+            logits, pooled = runner(eng, 0, B)
+            return eng, logits, pooled, eng.scores
+        cur = torch.cuda.current_stream(dev)
+        if (str(dev), ns) not in self._side:
+            self._side[(str(dev), ns)] = [torch.cuda.Stream(dev) for _ in range(ns)]
+        side = self._side[(str(dev), ns)]
+        parts = []
+        for slot in range(ns):
+            lo, hi = slot * B // ns, (slot + 1) * B // ns
+            side[slot].wait_stream(cur)                       # the caller's input is ready
+            with torch.cuda.stream(side[slot]):
+                eng = self._engine(dtype, hi - lo, dims, dev, slot=slot)
+                logits, pooled = runner(eng, lo, hi)
+                parts.append((eng, logits, pooled, eng.scores))
+        for s in side:
+            cur.wait_stream(s)
+        cat = lambda i: None if parts[0][i] is None else torch.cat([p[i] for p in parts])
+        return parts[0][0], cat(1), cat(2), cat(3)
 
     def forward(self, images, noise=None, has_mask=None, freeze_backbone=False, return_feature_maps=False, return_scores=False):
         assert not freeze_backbone
@@ -187,18 +220,17 @@ class I3D8x8(_HipNetwork):
         if B == 0:                                   # an empty batch is an empty answer (no launch)
             return {"final_output": x.new_zeros((0, self.spec.num_classes))}
         with torch.cuda.device(x.device):
-            eng = self._engine(self._select_dtype(), B, (T, H, W), x.device)
-            logits, pooled = eng.run_f32(x)
+            eng, logits, pooled, scores = self._run(B, (T, H, W), x.device, lambda e, lo, hi: e.run_f32(x[lo:hi]))
             out = {"final_output": self._finish(eng, logits, pooled, B)}
             if return_scores:                        # not a reference argument: the callers' sigmoid, from the head kernel
-                out["scores"] = self._scores_of(eng, B)
+                out["scores"] = self._scores_of(eng, scores, B)
         return out
 
     @staticmethod
-    def _scores_of(eng, B):
-        if eng.scores is None or eng.head_positions != 1:
+    def _scores_of(eng, scores, B):
+        if scores is None or eng.head_positions != 1:
             raise ValueError("scores are defined for a 1- or 2-class head on a crop with one head position")
-        return eng.scores.clone().view(B)
+        return scores.clone().view(B)
 
     def forward_clips_u8(self, clips_bthwc: torch.Tensor, mean=None, std=None, return_scores=False, return_pooled=False):
         """Fused caller prologue: uint8 (B,T,H,W,3) 0..255 RGB clips straight from the aligner; replaces
@@ -214,11 +246,11 @@ class I3D8x8(_HipNetwork):
         dev = clips_bthwc.device
         B, T, H, W, _ = clips_bthwc.shape
         with torch.cuda.device(dev):
-            eng = self._engine(self._select_dtype(), B, (T, H, W), dev)
-            logits, pooled = eng.run_u8(clips_bthwc.contiguous(), mean, std)
+            clips = clips_bthwc.contiguous()
+            eng, logits, pooled, scores = self._run(B, (T, H, W), dev, lambda e, lo, hi: e.run_u8(clips[lo:hi], mean, std))
             out = {"final_output": self._finish(eng, logits, pooled, B)}
             if return_scores:
-                out["scores"] = self._scores_of(eng, B)
+                out["scores"] = self._scores_of(eng, scores, B)
             if return_pooled:
                 out["pooled"] = pooled.clone().view(B, -1)
         return out
@@ -336,9 +368,11 @@ class Classifier(nn.Module):
     name = "i3d_ori"
 
     def __init__(self, clip_size: int = 32, imsize: int = 224, precision: str = "auto",
-                 model_dir: Optional[str] = None, crop_size: int = 224):
+                 model_dir: Optional[str] = None, crop_size: int = 224, streams: Optional[int] = None):
         super().__init__()
         self._build_kwargs = dict(clip_size=clip_size, imsize=imsize, precision=precision, crop_size=crop_size)
+        if streams is not None:
+            self._build_kwargs["streams"] = streams
         self.model_dir = model_dir
         self.network = self.build_network()
         self._warped_network = self.network

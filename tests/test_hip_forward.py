@@ -347,3 +347,24 @@ def test_infer_scores_matches_callers_epilogue(clf32, weights0):
     with torch.inference_mode():
         out = clf32.network.forward_clips_u8(u8.cuda(), return_scores=True, return_pooled=True)
     assert out["pooled"].shape == (2, 2048) and torch.allclose(out["scores"], torch.sigmoid(out["final_output"]).view(2), atol=1e-6)
+
+
+def test_two_stream_mode_matches_single_stream(weights0):
+    """Classifier(streams=2): a batch of >= 16 clips runs as two half-batches on two HIP streams (two engines); same logits as the
+    single-stream engine up to the kernel choices that depend on the batch size, same golden tolerance; odd batches split 8 + 9."""
+    g = load_json("f1b_logits.json")["batch16"]
+    u8 = synth.synthetic_clips_u8(16, seed=g["seed"], kind=g["kind"]).cuda()
+    want = torch.tensor(g["logits_f32"])
+    clf2 = Classifier(precision="f16", streams=2)
+    clf2.network.load_state_dict(weights0)
+    clf2 = clf2.cuda().eval()
+    with torch.inference_mode():
+        out = clf2.network.forward_clips_u8(u8, return_scores=True, return_pooled=True)
+        y = out["final_output"].cpu().flatten()
+        y17 = clf2(synth.normalize_like_callers(torch.cat([u8, u8[:1]])))["final_output"].cpu().flatten()
+        torch.cuda.synchronize()
+    assert ("f16", 8, (32, 224, 224)) in clf2.network._engines and ("f16", 8, (32, 224, 224), 1) in clf2.network._engines
+    assert (y - want).abs().max().item() <= LOGIT_TOL["f16"]
+    assert out["scores"].shape == (16,) and out["pooled"].shape == (16, 2048)
+    assert torch.allclose(out["scores"].cpu(), torch.sigmoid(y), atol=1e-6)
+    assert y17.shape == (17,) and (y17[:16] - want).abs().max().item() <= LOGIT_TOL["f16"] and abs(float(y17[16] - want[0])) <= LOGIT_TOL["f16"]

@@ -62,6 +62,16 @@ def main():
             y = run(sd, x, dt, rw, ra)
             print("%-5s %-6s max|d| %.3e   d = %s" % (name, tag, (y - exact).abs().max().item(),
                                                       ["%.2e" % v for v in (y - exact).flatten().tolist()]))
+    # the weight rounding alone, one group of conv weights at a time (bf16)
+    rd = lambda t: t.to(torch.bfloat16).float()
+    groups = [("W(%s)" % st, (lambda k, st=st: k.split(".")[1] == st)) for st in allst] + \
+             [("W(%s)" % cls, (lambda k, cls=cls: k.endswith(cls) and ".s1." not in k))
+              for cls in (".a.weight", ".b.weight", ".c.weight", "branch1.weight")]
+    for tag, pred in groups:
+        sdw = {k: (rd(v) if (v.dim() == 5 and pred(k)) else v) for k, v in sd.items()}
+        y = oracle.forward(sdw, x)
+        n = sum(1 for k, v in sd.items() if v.dim() == 5 and pred(k))
+        print("bf16  %-18s %2d layers  d = %s" % (tag, n, ["%+.2e" % v for v in (y - exact).flatten().tolist()]))
 
 
 if __name__ == "__main__":
