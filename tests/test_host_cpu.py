@@ -203,3 +203,49 @@ def test_aligner_host_fit_matches_reference():
         np.testing.assert_allclose(trans, g[tag + "_trans"], rtol=1e-10, atol=1e-10)
     with pytest.raises(Exception, match="twoUniquePointsReq"):
         aligner.estimate_batch_transform(g["t1_256_ldm5"], np.zeros((5, 2)))       # rank-deficient targets (cp2tform's error)
+
+
+def _desc(n, t, h, w, cin, cout, k, s, p, dtype=1, relu=1):
+    from af_mi355x import _lib
+    d = _lib.ConvDesc()
+    d.n, d.t, d.h, d.w, d.cin, d.cout = n, t, h, w, cin, cout
+    d.kt, d.kh, d.kw = k
+    d.st, d.sh, d.sw = s
+    d.pt, d.ph, d.pw = p
+    d.to, d.ho, d.wo = [(a + 2 * pp - kk) // ss + 1 for a, pp, kk, ss in zip((t, h, w), p, k, s)]
+    d.relu, d.dtype = relu, dtype
+    return d
+
+
+def test_kernel_selection_and_workspace_sizing_are_host_logic():
+    """af_conv_variant / af_conv_workspace_bytes / af_conv_bc_fusable run on the host (no GPU): the s3 / s4 `b` convs take the
+    frame-resident halo kernel at bench batch sizes and the generic kernel (+ split-K scratch) for a live call's one clip."""
+    import ctypes as C
+    from af_mi355x import _lib
+    L = _lib.lib
+    name = lambda d: L.af_conv_variant_name(L.af_conv_variant(C.byref(d), None)).decode()
+    s4b = lambda n, dt=1: _desc(n, 16, 14, 14, 256, 256, (1, 3, 3), (1, 1, 1), (0, 1, 1), dt)
+    s3b = lambda n: _desc(n, 16, 28, 28, 128, 128, (1, 3, 3), (1, 1, 1), (0, 1, 1))
+    assert name(s4b(16)).startswith("conv133g") and name(s3b(16)).startswith("conv133g") and name(s3b(8)).startswith("conv133g")
+    assert name(s4b(8)).startswith("conv_igemm") and name(s4b(1)).startswith("conv_igemm")      # 128 / 16 frames: too few units
+    assert name(s4b(16, 0)).startswith("conv_igemm")                                            # fp32: generic kernel
+    assert name(_desc(16, 16, 28, 28, 128, 128, (1, 3, 3), (1, 2, 2), (0, 1, 1))).startswith("conv_igemm")   # stride 2
+    assert name(_desc(16, 32, 56, 56, 64, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1))).startswith("conv133_c64")
+    # split-K scratch: one clip in s4 / s5 splits, a full batch does not
+    assert L.af_conv_workspace_bytes(C.byref(s4b(1))) > 0 and L.af_conv_workspace_bytes(C.byref(s4b(16))) == 0
+    s5b = _desc(1, 16, 7, 7, 512, 512, (1, 3, 3), (1, 1, 1), (0, 1, 1))
+    assert L.af_conv_workspace_bytes(C.byref(s5b)) == 4 * 784 * 512 * 4                        # 56 tiles -> 4 K ranges of fp32 partial sums
+    # b + c fusion is offered exactly where the halo kernel runs and c is a plain 1x1x1 over b's output
+    c4 = lambda n: _desc(n, 16, 14, 14, 256, 1024, (1, 1, 1), (1, 1, 1), (0, 0, 0))
+    assert L.af_conv_bc_fusable(C.byref(s4b(16)), C.byref(c4(16))) == 1
+    assert L.af_conv_bc_fusable(C.byref(s4b(1)), C.byref(c4(1))) == 0
+    assert L.af_conv_bc_fusable(C.byref(s4b(16)), C.byref(_desc(16, 16, 14, 14, 128, 1024, (1, 1, 1), (1, 1, 1), (0, 0, 0)))) == 0
+
+
+def test_rgb3_stem_sizes():
+    from af_mi355x import _lib
+    L = _lib.lib
+    row = ((224 + 8) * 6 + 15) // 16 * 16
+    assert L.af_stem_input_bytes_rgb3(1, 32, 224, 224, 1) == (36 * 230 + 8) * row
+    assert L.af_packed_stem_weight_bytes_rgb3(5, 1) == 27 * 4 * 64 * 16 and L.af_packed_stem_weight_bytes_rgb3(1, 2) == 6 * 4 * 64 * 16
+    assert L.af_stem_input_bytes_rgb3(1, 32, 224, 224, 0) < 0                                  # fp32 keeps the 4-channel layout
