@@ -56,7 +56,13 @@ __global__ __launch_bounds__(256, 1) void conv133_c64_kernel(const C133Args a) {
     char* otile = reinterpret_cast<char*>(smem) + 2 * buf_bytes;
 
     // ---- weights -> registers (A operand: lane = (channel row, k-group))
-    uint4 wreg[9][2][NT4];
+    // 288 registers of weights do not fit the 256 VGPRs next to the accumulators and fragments; left to itself hipcc parks
+    // the overflow in AGPRs and copies it back with one v_accvgpr_read PER REGISTER PER USE (282 copies for the 288 MFMAs of a
+    // strip: with one wave per SIMD every one of them is an issue slot the MFMA stream loses).  An MFMA can take its A
+    // operand straight from an AGPR: the empty asm below pins the first AGPR_FRAGS fragments there for the life of the
+    // workgroup, the rest stay in VGPRs, and the loop has no copies at all.
+    constexpr int AGPR_FRAGS = 44;
+    u32x4 wreg[9][2][NT4];
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
@@ -64,7 +70,9 @@ __global__ __launch_bounds__(256, 1) void conv133_c64_kernel(const C133Args a) {
 #pragma unroll
             for (int i = 0; i < NT4; ++i) {
                 const int ch = i * 16 + frow;
-                wreg[tap][kk][i] = *reinterpret_cast<const uint4*>(a.w + ((ch * 9 + tap) * 64 + kk * 32 + fg * 8) * 2);
+                wreg[tap][kk][i] = *reinterpret_cast<const u32x4*>(a.w + ((ch * 9 + tap) * 64 + kk * 32 + fg * 8) * 2);
+                if ((tap * 2 + kk) * NT4 + i < AGPR_FRAGS) asm volatile("" : "+a"(wreg[tap][kk][i]));
+                else asm volatile("" : "+v"(wreg[tap][kk][i]));
             }
     // BN scale / shift wait in LDS (the weights take 144 VGPRs; a spill would put scratch loads - and their
     // vmcnt(0), which also waits for the patch DMA in flight - into the strip loop)
@@ -161,7 +169,7 @@ __global__ __launch_bounds__(256, 1) void conv133_c64_kernel(const C133Args a) {
 #pragma unroll
             for (int k = 0; k < MT; ++k)
 #pragma unroll
-                for (int i = 0; i < NT4; ++i) Mma<DT>::run(wreg[step >> 1][step & 1][i], bf[step & 1][k], acc[i][k]);
+                for (int i = 0; i < NT4; ++i) Mma<DT>::run(__builtin_bit_cast(uint4, wreg[step >> 1][step & 1][i]), bf[step & 1][k], acc[i][k]);
             __builtin_amdgcn_sched_barrier(0);
         }
 
