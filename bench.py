@@ -107,7 +107,11 @@ def roofline_report(eng, args, line, reps=5):
     per_kernel, per_class, eng_bytes, kernel_ops, variants = {}, {}, {}, {}, {}
     for i in range(eng.n_ops):
         op = eng.ops[i]
-        if op.kind == _lib.AF_OP_CONV_BC:                # b input + c output + residual + both weights; the b output stays on chip
+        if op.kind == _lib.AF_OP_CONV_CA:                # b tile + residual + trunk out + a out + both weights; the trunk is not re-read
+            cc_, ca = op.conv, op.conv2
+            pos = cc_.n * cc_.to * cc_.ho * cc_.wo
+            eng_bytes[i] = es * (pos * cc_.cin + 2 * pos * cc_.cout + pos * ca.cout + cc_.cout * cc_.cin + ca.cout * ca.cin * 3)
+        elif op.kind == _lib.AF_OP_CONV_BC:              # b input + c output + residual + both weights; the b output stays on chip
             cb, cc_ = op.conv, op.conv2
             pos = cb.n * cb.to * cb.ho * cb.wo
             eng_bytes[i] = es * (pos * cb.cin + pos * cc_.cout * (2 if op.residual else 1) + cb.cout * cb.cin * 9 + cc_.cout * cc_.cin)
@@ -130,6 +134,8 @@ def roofline_report(eng, args, line, reps=5):
         if op.kind in (_lib.AF_OP_CONV, _lib.AF_OP_CONV_DUAL):
             d2 = C.byref(op.conv2) if op.kind == _lib.AF_OP_CONV_DUAL else None
             kname = _lib.lib.af_conv_variant_name(_lib.lib.af_conv_variant(C.byref(op.conv), d2)).decode()
+        elif op.kind == _lib.AF_OP_CONV_CA:
+            kname = "conv_ca<c(i) -> a(i+1) fused>"
         elif op.kind == _lib.AF_OP_CONV_BC:
             kname = "conv133g<b + c fused>"
         elif op.kind in (_lib.AF_OP_STEM, _lib.AF_OP_STEM_POOL, _lib.AF_OP_STEM3_POOL, _lib.AF_OP_TSTEM):

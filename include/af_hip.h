@@ -185,6 +185,19 @@ int af_conv3d_bc_bn_act(const af_conv_desc* db, const void* in, const void* wb_p
                         const af_conv_desc* dc, const void* wc_packed, const float* scale_c, const float* shift_c,
                         const void* residual, void* out, int out_ld, void* stream);
 
+/* The END of one res block and the START of the next, across the block boundary, as ONE launch (s2, 16-bit):
+ *     x     = relu( bn_c(conv1x1x1_c(b)) + residual )      resnet_helper.py:304-325, 438-444   -> out_x  [n][t][h][w][C]
+ *     a_out = relu( bn_a(conv3x1x1_a(x)) )                  resnet_helper.py:267-281 (next block) -> out_a [n][t][h][w][64]
+ * in the time-tiled layout of the 3x1x1 kernel (tile = all T frames of a few pixels: the temporal halo is inside the tile):
+ * per 64-channel slab of the trunk the residual is fetched, the c conv's slab is computed and added in LDS, stored once and
+ * multiplied by the three temporal taps there - the `a` conv no longer re-reads the trunk from HBM.  dc: 64 -> C channels
+ * (C % 64 == 0), residual required, ReLU; da: C -> 64, kernel [3,1,1], pad [1,0,0]; T = 16 or 32; batches with >= 4 tiles per
+ * CU (af_conv_ca_fusable says whether a pair qualifies). */
+int af_conv_ca_fusable(const af_conv_desc* dc, const af_conv_desc* da);
+int af_conv3d_ca_bn_act(const af_conv_desc* dc, const void* in_b, const void* wc_packed, const float* scale_c, const float* shift_c,
+                        const void* residual, void* out_x, const af_conv_desc* da, const void* wa_packed, const float* scale_a,
+                        const float* shift_a, void* out_a, void* stream);
+
 /* which tile variant af_conv3d_[dual_]bn_act launches for `d` (+ optional `d2`) (>= 0) and its kernel name:
  * lets a profiler attribute per-layer device time and FLOPs to a kernel instantiation (bench.py roofline). */
 int af_conv_variant(const af_conv_desc* d, const af_conv_desc* d2);
@@ -307,7 +320,10 @@ enum af_op_kind { AF_OP_STEM = 0, AF_OP_CONV = 1, AF_OP_MAXPOOL = 2, AF_OP_HEAD 
                      shift2 = the c conv, residual, out, out_ld (af_conv3d_bc_bn_act) */
                   AF_OP_CONV_BC = 15,
                   /* the K-packed stem path: same fields as PACK_F32 / PACK_U8 / STEM_POOL, rgb3 input layout */
-                  AF_OP_PACK3_F32 = 16, AF_OP_PACK3_U8 = 17, AF_OP_STEM3_POOL = 18 };
+                  AF_OP_PACK3_F32 = 16, AF_OP_PACK3_U8 = 17, AF_OP_STEM3_POOL = 18,
+                  /* c of a block + a of the next in one launch: conv / weight / scale / shift / residual / out = the c conv and
+                     the trunk, conv2 / weight2 / scale2 / shift2 / aux = the a conv and its output (af_conv3d_ca_bn_act) */
+                  AF_OP_CONV_CA = 19 };
 
 typedef struct af_op {
     int32_t kind;                    /* af_op_kind */

@@ -1,0 +1,286 @@
+// c(i) -> a(i+1) across a block boundary of s2, as ONE launch (16-bit operands):
+//     x    = relu( bn_c(conv1x1x1_c(b)) + res )        the end of ResBlock i   (resnet_helper.py:304-325, 438-444)
+//     aout = relu( bn_a(conv3x1x1_a(x)) )              the first conv of ResBlock i+1 (resnet_helper.py:267-281)
+// b: [N][T][HW][64], res / x: [N][T][HW][C] (C = 256 in s2), aout: [N][T][HW][64].
+//
+// s2 is an HBM stream: per block the 822-MB trunk is written by `c`, read back by the next block's `a`, and
+// read a third time as the residual.  The temporal conv needs frames t-1, t, t+1 of the SAME pixel, so conv311 already
+// tiles M as (clip, P pixels, ALL T frames): a tile holds its own temporal halo.  This kernel keeps that tile and
+// PRODUCES its K-slab image instead of fetching it: per 64-channel slab of the trunk the residual slab is DMA'd into the
+// image rows, the c conv's 64 output channels of that slab are computed from the b tile (K = 64: 16 MFMAs per wave) and
+// added in place (BN, + residual, ReLU, the one rounding), the finished slab is stored to HBM as whole 128-byte rows (the
+// trunk must exist: it is the next residual) and multiplied by the three temporal taps right there.  The `a` conv's
+// 822-MB read disappears: 2.05 GB per pair instead of 2.88.
+// Persistent workgroups, stage stream across tiles (2-slot ring: a-weights of the slab + the image), the b tile of the
+// next tile fetched under the last slab; c weights go global -> registers one stage ahead; BN parameters sit in LDS (a plain
+// global load between the DMA issue and its use would make hipcc wait for the DMA in flight).
+#include "af_common.h"
+
+namespace af {
+
+struct CAArgs {
+    const char* inb;     // [N][T][HW][64]
+    const char* wc;      // packed [C][64]
+    const float* scale_c;
+    const float* shift_c;
+    const char* res;     // [N][T][HW][C]
+    char* outx;          // [N][T][HW][C]
+    const char* wa;      // packed [64][3][C]
+    const float* scale_a;
+    const float* shift_a;
+    char* outa;          // [N][T][HW][64]
+    int T, HW, C, kslabs;
+    int P, chunks, tiles;
+};
+
+template <int DT>
+__global__ __launch_bounds__(512, 2) void conv_ca_kernel(const CAArgs a) {
+    typedef Elem<DT> E;
+    static_assert(E::EPC == 8, "16-bit operands only");
+    constexpr int BM = 256, TN = 4, TM = 2;
+    constexpr int WROWS = 3 * 64;                      // a-weight rows per stage: (dt, channel)
+    constexpr int WPIECES = WROWS / 64;                // DMA pieces per wave
+    constexpr int XPW = 5;                             // image pieces per wave (rows BM + 2P <= 288)
+    constexpr int BPW = BM / 64;                       // b-tile pieces per wave
+
+    extern __shared__ uint4 smem[];
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int frow = lane & 15, fg = lane >> 4;
+    const int P = a.P, XR = BM + 2 * P, XP = XR >> 3;
+    const int stage_bytes = (WROWS + XR) * 128;
+    char* sm = reinterpret_cast<char*>(smem);
+    char* btile = sm + 2 * stage_bytes;                // [256 rows][64 ch], swizzled
+    float* bnp = reinterpret_cast<float*>(btile + BM * 128);    // scale_c[C] shift_c[C] scale_a[64] shift_a[64]
+    const int wm = wave;                               // 32-row group of the tile
+
+    for (int i = tid; i < a.C; i += 512) { bnp[i] = a.scale_c[i]; bnp[a.C + i] = a.shift_c[i]; }
+    if (tid < 64) { bnp[2 * a.C + tid] = a.scale_a[tid]; bnp[2 * a.C + 64 + tid] = a.shift_a[tid]; }
+
+    // ---- producer state
+    const int drow = lane >> 3, chunk = (lane & 7) ^ drow;
+    const long long Kw = 3LL * a.C;                                  // a-weight row length (elements)
+    const i32x4 wdesc = make_desc(a.wa);
+    unsigned woff[WPIECES];
+#pragma unroll
+    for (int i = 0; i < WPIECES; ++i) {
+        const int row = (wave + 8 * i) * 8 + drow, dt = row / 64, ch = row % 64;
+        woff[i] = (unsigned)((ch * Kw + (long long)dt * a.C) * 2 + chunk * 16);
+    }
+    unsigned xoff[XPW];
+    int xp[XPW];
+#pragma unroll
+    for (int i = 0; i < XPW; ++i) {
+        const int row = (wave + 8 * i) * 8 + drow;
+        const int t = row / P - 1, p = row % P;
+        xp[i] = p;
+        xoff[i] = (t >= 0 && t < a.T && row < XR) ? (unsigned)((((long long)t * a.HW + p) * a.C) * 2 + chunk * 16) : kOutOfRange;
+    }
+    unsigned boff[BPW];
+    int bp[BPW];
+#pragma unroll
+    for (int i = 0; i < BPW; ++i) {
+        const int row = (wave + 8 * i) * 8 + drow;
+        const int t = row / P, p = row % P;
+        bp[i] = p;
+        boff[i] = (unsigned)((((long long)t * a.HW + p) * 64) * 2 + chunk * 16);
+    }
+    const long long clipx = (long long)a.T * a.HW * a.C * 2, clipb = (long long)a.T * a.HW * 64 * 2;
+
+    const int my_tiles = (a.tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int total = my_tiles * a.kslabs;
+    int p_tile = blockIdx.x, p_kc = 0;                               // producer cursor
+    auto issue_stage = [&](int slot) {
+        const int n = p_tile / a.chunks, hw0 = (p_tile % a.chunks) * P;
+        const i32x4 xdesc = make_desc(a.res + n * clipx + (long long)hw0 * a.C * 2);
+        const unsigned base = lds0 + slot * stage_bytes + wave * (8 * 128);
+        const int soff = p_kc * 128;
+#pragma unroll
+        for (int i = 0; i < WPIECES; ++i) blds16(woff[i], wdesc, soff, base + i * (64 * 128));
+#pragma unroll
+        for (int i = 0; i < XPW; ++i)
+            if (wave + 8 * i < XP)
+                blds16(hw0 + xp[i] < a.HW ? xoff[i] : kOutOfRange, xdesc, soff, base + WROWS * 128 + i * (64 * 128));
+        if (++p_kc == a.kslabs) { p_kc = 0; p_tile += gridDim.x; }
+    };
+    auto issue_btile = [&](int tile) {
+        const int n = tile / a.chunks, hw0 = (tile % a.chunks) * P;
+        const i32x4 bdesc = make_desc(a.inb + n * clipb + (long long)hw0 * 64 * 2);
+        const unsigned base = lds0 + 2 * stage_bytes + wave * (8 * 128);
+#pragma unroll
+        for (int i = 0; i < BPW; ++i) blds16(hw0 + bp[i] < a.HW ? boff[i] : kOutOfRange, bdesc, 0, base + i * (64 * 128));
+    };
+    // c weights of a stage: 4 channel tiles x 2 k-halves, global -> registers
+    uint4 wcur[TN][2], wnext[TN][2];
+    auto load_wc = [&](uint4 (&dst)[TN][2], int kc) {
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+                dst[i][kk] = *reinterpret_cast<const uint4*>(a.wc + ((long long)(kc * 64 + i * 16 + frow) * 64 + kk * 32 + fg * 8) * 2);
+    };
+
+    f32x4 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (total > 0) {
+        load_wc(wnext, 0);
+        issue_btile(blockIdx.x);
+        issue_stage(0);
+    }
+    __syncthreads();                                                 // BN parameters visible
+    int c_tile = blockIdx.x, c_kc = 0;                               // consumer cursor
+    bool after_last = false;
+    for (int q = 0; q < total; ++q) {
+        const int slot = q & 1;
+        // stage q (and, at a tile's first slab, its b tile) has landed once at most the younger stores of the previous
+        // iteration are still in flight: 4 trunk-row stores, + 8 `a` output stores behind a tile's last slab
+        if (q == 0) wait_vmcnt<0>();
+        else if (after_last) wait_vmcnt<12>();
+        else wait_vmcnt<4>();
+        __builtin_amdgcn_s_barrier();                                // ... for everyone; slot ^ 1 is no longer read
+#pragma unroll
+        for (int i = 0; i < TN; ++i) { wcur[i][0] = wnext[i][0]; wcur[i][1] = wnext[i][1]; }
+        if (q + 1 < total) {
+            load_wc(wnext, c_kc + 1 == a.kslabs ? 0 : c_kc + 1);     // BEFORE the DMA issue: hipcc's wait for these loads must not cover it
+            __builtin_amdgcn_sched_barrier(0);
+            issue_stage(slot ^ 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const int n = c_tile / a.chunks, hw0 = (c_tile % a.chunks) * P;
+        char* img = sm + slot * stage_bytes + WROWS * 128;           // image rows: (t + 1) * P + p
+        // ---- c conv, 64 trunk channels of this slab, in place: image = relu(bn_c(Wc b) + image)
+        {
+            f32x4 cc[TN][TM];
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j) cc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const uint4* bs = reinterpret_cast<const uint4*>(btile) + (wm * 32 + frow) * 8;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int c = (kk * 4 + fg) ^ (frow & 7);
+                uint4 bf[TM];
+#pragma unroll
+                for (int j = 0; j < TM; ++j) bf[j] = bs[j * 16 * 8 + c];
+#pragma unroll
+                for (int i = 0; i < TN; ++i)
+#pragma unroll
+                    for (int j = 0; j < TM; ++j) Mma<DT>::run(wcur[i][kk], bf[j], cc[i][j]);
+            }
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(bnp + c_kc * 64 + i * 16 + fg * 4);
+                const f32x4 sf = *reinterpret_cast<const f32x4*>(bnp + a.C + c_kc * 64 + i * 16 + fg * 4);
+#pragma unroll
+                for (int j = 0; j < TM; ++j) {
+                    const int R = P + wm * 32 + j * 16 + frow;       // image row of this position (R & 7 == frow & 7: P % 8 == 0)
+                    char* cell = img + R * 128 + (((i * 2 + (fg >> 1)) ^ (frow & 7)) << 4) + (fg & 1) * 8;
+                    f32x4 v = cc[i][j] * sc + sf + Vec4<DT>::load(cell);
+                    v[0] = relu_f(v[0]); v[1] = relu_f(v[1]); v[2] = relu_f(v[2]); v[3] = relu_f(v[3]);
+                    Vec4<DT>::store(cell, v);
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                // the slab of x is complete (raw barrier: the DMA stays in flight)
+        const bool last = c_kc + 1 == a.kslabs;
+        if (last && q + 1 < total) issue_btile(c_tile + gridDim.x);  // the b tile is dead: fetch the next tile's under this slab
+        // ---- the finished slab leaves for HBM as whole 128-byte row segments
+        {
+            char* ox = a.outx + ((long long)n * a.T * a.HW + hw0) * a.C * 2 + c_kc * 128;
+#pragma unroll
+            for (int it = 0; it < BM * 8 / 512; ++it) {
+                const int row = (tid >> 3) + 64 * it, ck = tid & 7;
+                const int t = row / P, p = row - t * P;
+                const u32x4 o = *reinterpret_cast<const u32x4*>(img + (P + row) * 128 + ((ck ^ ((P + row) & 7)) << 4));
+                if (hw0 + p < a.HW)
+                    __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(ox + ((long long)t * a.HW + p) * a.C * 2 + ck * 16));
+            }
+        }
+        // ---- a conv: three temporal taps of the slab
+        const uint4* ws = smem + slot * (stage_bytes / 16) + frow * 8;
+        const uint4* xs = smem + slot * (stage_bytes / 16) + WROWS * 8 + (wm * 32 + frow) * 8;
+#pragma unroll
+        for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int c = (kk * 4 + fg) ^ (frow & 7);
+                uint4 af[TN], bf[TM];
+#pragma unroll
+                for (int i = 0; i < TN; ++i) af[i] = ws[(dt * 64 + i * 16) * 8 + c];
+#pragma unroll
+                for (int j = 0; j < TM; ++j) bf[j] = xs[(dt * P + j * 16) * 8 + c];
+#pragma unroll
+                for (int i = 0; i < TN; ++i)
+#pragma unroll
+                    for (int j = 0; j < TM; ++j) Mma<DT>::run(af[i], bf[j], acc[i][j]);
+            }
+        after_last = last;
+        if (!last) { ++c_kc; continue; }
+
+        // ---- tile finished: BN + ReLU + the one rounding, 8 bytes per lane straight from the accumulators (a 32-KB tile of
+        // a 320-KB tile's traffic: not worth an LDS transposition that would compete with the b tile for space)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            const int r = wm * 32 + j * 16 + frow;                   // tile row = t * P + p
+            const int t = r / P, p = r - t * P;
+            const long long pos = ((long long)n * a.T + t) * a.HW + hw0 + p;
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(bnp + 2 * a.C + i * 16 + fg * 4);
+                const f32x4 sf = *reinterpret_cast<const f32x4*>(bnp + 2 * a.C + 64 + i * 16 + fg * 4);
+                f32x4 v = acc[i][j] * sc + sf;
+                v[0] = relu_f(v[0]); v[1] = relu_f(v[1]); v[2] = relu_f(v[2]); v[3] = relu_f(v[3]);
+                if (hw0 + p < a.HW) Vec4<DT>::store(a.outa + (pos * 64 + i * 16 + fg * 4) * 2, v);
+                acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        c_kc = 0; c_tile += gridDim.x;
+    }
+}
+
+template <int DT>
+static int launch_ca(const CAArgs& a, int blocks, hipStream_t stream) {
+    const int lds = 2 * (3 * 64 + 256 + 2 * a.P) * 128 + 256 * 128 + (2 * a.C + 128) * 4;
+    if (lds > 160 * 1024) return set_error(AF_ERR_ARG, "conv_ca: %d bytes of LDS needed", lds);
+    AF_SET_MAX_LDS((&conv_ca_kernel<DT>), 160 * 1024, "conv_ca");
+    hipLaunchKernelGGL((conv_ca_kernel<DT>), dim3(blocks), dim3(512), lds, stream, a);
+    AF_CHECK_LAUNCH("conv_ca_kernel");
+    return AF_OK;
+}
+
+// dc: the 1x1x1 `c` conv (64 -> C, with residual + ReLU), da: the 3x1x1 `a` conv of the next block (C -> 64) over its output
+bool conv_ca_applies(const af_conv_desc* dc, const af_conv_desc* da) {
+    if (!dc || !da || dc->dtype == AF_F32 || da->dtype != dc->dtype || dc->tpool || da->tpool) return false;
+    if (dc->kt != 1 || dc->kh != 1 || dc->kw != 1 || dc->st != 1 || dc->sh != 1 || dc->sw != 1 || dc->pt || dc->ph || dc->pw) return false;
+    if (da->kt != 3 || da->kh != 1 || da->kw != 1 || da->st != 1 || da->sh != 1 || da->sw != 1 || da->pt != 1 || da->ph || da->pw) return false;
+    if (dc->cin != 64 || da->cout != 64 || dc->cout != da->cin || dc->cout % 64 != 0 || dc->cout > 1024 || !dc->relu || !da->relu) return false;
+    if (dc->n != da->n || dc->t != da->t || dc->h != da->h || dc->w != da->w) return false;
+    if (dc->t != 16 && dc->t != 32) return false;                     // tile = all T frames x 256 / T pixels
+    const long long hw = (long long)dc->h * dc->w;
+    if ((long long)dc->t * hw * dc->cout * 2 >= (1LL << 31)) return false;     // 32-bit offsets inside a clip
+    const int p = 256 / dc->t;
+    const long long tiles = (long long)dc->n * ((hw + p - 1) / p);
+    // persistent stream: pays with several tiles per workgroup (small batches keep the two launches)
+    return tiles >= 4LL * device_cus() && tiles < (1LL << 31);
+}
+
+int conv_ca_run(const af_conv_desc* dc, const void* inb, const void* wc, const float* scale_c, const float* shift_c,
+                const void* residual, void* outx, const af_conv_desc* da, const void* wa, const float* scale_a,
+                const float* shift_a, void* outa, hipStream_t stream) {
+    CAArgs a;
+    a.inb = (const char*)inb; a.wc = (const char*)wc; a.scale_c = scale_c; a.shift_c = shift_c; a.res = (const char*)residual;
+    a.outx = (char*)outx; a.wa = (const char*)wa; a.scale_a = scale_a; a.shift_a = shift_a; a.outa = (char*)outa;
+    a.T = dc->t; a.HW = dc->h * dc->w; a.C = dc->cout; a.kslabs = dc->cout / 64;
+    a.P = 256 / dc->t; a.chunks = (a.HW + a.P - 1) / a.P; a.tiles = dc->n * a.chunks;
+    const int cus = device_cus();
+    const int blocks = a.tiles < cus ? a.tiles : cus;
+    return dc->dtype == AF_BF16 ? launch_ca<AF_BF16>(a, blocks, stream) : launch_ca<AF_F16>(a, blocks, stream);
+}
+
+}  // namespace af

@@ -20,10 +20,10 @@ _TORCH_DTYPE = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float
 
 # op tags (echoed by the timed runner; used by bench.py to attribute device time to kernel classes)
 TAG_PACK, TAG_STEM, TAG_POOL, TAG_HEAD = 0, 1, 2, 3
-TAG_CONV_1x1x1, TAG_CONV_Tx1x1, TAG_CONV_1x3x3, TAG_CONV_OTHER, TAG_CONV_BC = 10, 11, 12, 13, 14
+TAG_CONV_1x1x1, TAG_CONV_Tx1x1, TAG_CONV_1x3x3, TAG_CONV_OTHER, TAG_CONV_BC, TAG_CONV_CA = 10, 11, 12, 13, 14, 15
 TAG_NAMES = {TAG_PACK: "input_pack", TAG_STEM: "stem_5x7x7", TAG_POOL: "maxpool", TAG_HEAD: "head",
              TAG_CONV_1x1x1: "conv_1x1x1", TAG_CONV_Tx1x1: "conv_3x1x1", TAG_CONV_1x3x3: "conv_1x3x3",
-             TAG_CONV_OTHER: "conv_other", TAG_CONV_BC: "conv_1x3x3+1x1x1_fused"}
+             TAG_CONV_OTHER: "conv_other", TAG_CONV_BC: "conv_1x3x3+1x1x1_fused", TAG_CONV_CA: "conv_1x1x1+3x1x1_fused"}
 TAG_NAMES[TAG_STEM] = "stem"
 
 
@@ -187,15 +187,28 @@ class _Plan:
     def add(self, **e):
         self.entries.append(e)
 
+    def ca_fusable(self, c: ConvSpec, a_next: ConvSpec, db, dc) -> bool:
+        """does the library run this block's c conv (+ residual + ReLU) and the NEXT block's a conv as one launch (af_conv3d_ca_bn_act)?"""
+        if self.code is None or os.environ.get("AF_FUSE_CA", "1") != "1":
+            return False
+        d1, d2 = _lib.ConvDesc(), _lib.ConvDesc()
+        _fill_conv_desc(d1, self.batch, self.code, c, db, dc, True)
+        _fill_conv_desc(d2, self.batch, self.code, a_next, dc, a_next.out_dims(*dc), True)
+        return bool(lib.af_conv_ca_fusable(C.byref(d1), C.byref(d2)))
+
     def stage(self, stage, d, cur, nxt, a_buf, b_buf, last_ld=None, tpool_last=False):
         """One pathway's ResStage.  ``last_ld``: row stride of the stage's final output (room for the lateral's
         channels).  Returns (dims, channels, buffer holding the output, the other trunk buffer)."""
         c = None
         nblk = len(stage.blocks)
+        a_done = False                       # this block's a conv was run by the previous block's fused c -> a launch
         for bi, blk in enumerate(stage.blocks):
             last = bi == nblk - 1
             da = blk.a.out_dims(*d)
-            self.add(kind="conv", cv=blk.a, din=d, dout=da, src=cur, dst=a_buf); self.need(a_buf, da, blk.a.cout)
+            if not a_done:
+                self.add(kind="conv", cv=blk.a, din=d, dout=da, src=cur, dst=a_buf)
+            self.need(a_buf, da, blk.a.cout)
+            a_done = False
             db = blk.b.out_dims(*da)
             c_src, res_src = b_buf, cur
             pb = blk.b.pool_after_bn
@@ -243,6 +256,14 @@ class _Plan:
                 # c conv + projection shortcut in one launch; no shortcut tensor
                 assert blk.branch1.out_dims(*d) == dc
                 self.add(kind="dual", cv=blk.c, cv2=blk.branch1, din=db, din2=d, dout=dc, src=c_src, src2=cur, dst=nxt, ld=ld)
+            elif (not last and not tp and res_src == cur and ld == blk.c.cout and stage.blocks[bi + 1].a.pool_after_bn is None
+                  and self.ca_fusable(blk.c, stage.blocks[bi + 1].a, db, dc)):
+                # c + residual + ReLU of this block and the a conv of the next one in one launch (s2): the trunk slab is
+                # produced in LDS, stored once, and multiplied by the temporal taps without being read back
+                nxa = stage.blocks[bi + 1].a
+                self.add(kind="ca", cv=blk.c, cv2=nxa, din=db, dout=dc, src=c_src, res=res_src, dst=nxt, dst2=a_buf)
+                self.need(a_buf, nxa.out_dims(*dc), nxa.cout)
+                a_done = True
             else:
                 self.add(kind="conv", cv=blk.c, din=db, dout=dc, src=c_src, dst=nxt, res=res_src, ld=ld, tpool=tp)
             self.need(nxt, dstore, ld)
@@ -445,6 +466,20 @@ class Engine:
                 op.out_ld = e.get("ld", cv.cout)
                 self.op_names.append(cv.conv)
                 self.op_macs.append(batch * cv.macs(*e["din"]))
+            elif kind == "ca":
+                cvc, cva = e["cv"], e["cv2"]
+                op.kind, op.tag = _lib.AF_OP_CONV_CA, TAG_CONV_CA
+                fill_conv(op.conv, cvc, e["din"], e["dout"], True)
+                fill_conv(op.conv2, cva, e["dout"], cva.out_dims(*e["dout"]), True)
+                op.weight, op.scale, op.shift = (weights.w[cvc.conv].data_ptr(), weights.scale[cvc.conv].data_ptr(),
+                                                 weights.shift[cvc.conv].data_ptr())
+                op.weight2, op.scale2, op.shift2 = (weights.w[cva.conv].data_ptr(), weights.scale[cva.conv].data_ptr(),
+                                                    weights.shift[cva.conv].data_ptr())
+                op.residual = self.buf[e["res"]].data_ptr()
+                op.aux = self.buf[e["dst2"]].data_ptr()
+                op.out_ld = cvc.cout
+                self.op_names.append(cvc.conv + "->" + cva.conv.split("resnet.")[-1])
+                self.op_macs.append(batch * (cvc.macs(*e["din"]) + cva.macs(*e["dout"])))
             elif kind == "bc":
                 cvb, cvc = e["cv"], e["cv2"]
                 op.kind, op.tag = _lib.AF_OP_CONV_BC, TAG_CONV_BC
@@ -679,6 +714,8 @@ class Engine:
             shape = (op.conv.n, op.conv.to, (op.conv.ho - 1) // 2 + 1, (op.conv.wo - 1) // 2 + 1, op.conv.cout)
         elif op.kind == _lib.AF_OP_CONV_BC:
             shape = (op.conv2.n, op.conv2.to, op.conv2.ho, op.conv2.wo, op.out_ld or op.conv2.cout)
+        elif op.kind == _lib.AF_OP_CONV_CA:        # the trunk
+            shape = (op.conv.n, op.conv.to, op.conv.ho, op.conv.wo, op.conv.cout)
         elif op.kind in (_lib.AF_OP_STEM, _lib.AF_OP_CONV, _lib.AF_OP_CONV_DUAL, _lib.AF_OP_TSTEM):
             ld = op.out_ld or op.conv.cout
             q = 2 if op.conv.tpool == 2 else 1

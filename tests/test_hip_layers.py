@@ -473,3 +473,38 @@ def test_fused_b_c_vs_oracle(name, cin, cmid, cout, dims, use_res, dtype):
     tol = {"f16": 2e-3, "bf16": 1.6e-2}[dtype]                   # a b value on a rounding boundary may round the other way
     err = (got - want).abs().max().item()
     assert err <= tol * (want.abs().max().item() + 1e-9), "%s[%s] err %.3e" % (name, dtype, err)
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+@pytest.mark.parametrize("name,ctrunk,dims", [
+    ("s2_like_T32", 256, (2, 32, 64, 66)),        # T = 32: 8 pixels per tile, 4 K slabs; 1 056 tiles >= 4 per CU
+    ("ragged_T16", 128, (3, 16, 75, 77)),         # T = 16: 16 pixels per tile, HW = 5 775 = 360 x 16 + 15: ragged last chunk
+])
+def test_fused_c_a_vs_oracle(name, ctrunk, dims, dtype):
+    """af_conv3d_ca_bn_act: x = relu(bn_c(c(b)) + res) and a_out = relu(bn_a(a3x1x1(x))) in one launch (the trunk slab is
+    produced in LDS and multiplied by the temporal taps there) against the oracle's two conv_bn_act calls in fp64; the trunk
+    is rounded to the storage type on both sides before the temporal conv."""
+    seed = 5000 + sum(map(ord, name))
+    n, t, h, w = dims
+    lay = [("c.weight", (ctrunk, 64, 1, 1, 1), "float32"), ("a.weight", (64, ctrunk, 3, 1, 1), "float32")]
+    for p_, ch in (("c_bn", ctrunk), ("a_bn", 64)):
+        lay += [(p_ + s_, (ch,), "float32") for s_ in (".weight", ".bias", ".running_mean", ".running_var")]
+    sd = synth.fill_layout(lay, seed)
+    tdt = hh.TORCH_DT[dtype]
+    b = synth.synthetic_tensor((n, 64, t, h, w), seed).to(tdt).float()
+    res = synth.synthetic_tensor((n, ctrunk, t, h, w), seed + 1).to(tdt).float()
+    for k in ("c.weight", "a.weight"):
+        sd[k] = sd[k].to(tdt).float()
+    sd64 = {k: v.double() for k, v in sd.items()}
+    x = F.relu(oracle.conv_bn_act(b.double(), sd64["c.weight"], sd64, "c_bn", (1, 1, 1), (0, 0, 0), False) + res.double())
+    xr = x.to(tdt).double()                                     # the one rounding of the trunk
+    want_a = oracle.conv_bn_act(xr, sd64["a.weight"], sd64, "a_bn", (1, 1, 1), (1, 0, 0), True)
+    out = hh.conv_ca(hh.to_ndhwc(b, dtype), sd["c.weight"], hh.fold_bn(sd, "c_bn"), hh.to_ndhwc(res, dtype), sd["a.weight"],
+                     hh.fold_bn(sd, "a_bn"), dtype)
+    assert out is not None, "the library should fuse this pair"
+    got_x, got_a = hh.to_ncdhw(out[0]).double(), hh.to_ncdhw(out[1]).double()
+    tol = {"f16": 1.5e-3, "bf16": 1.2e-2}[dtype]
+    ex = (got_x - x).abs().max().item()
+    assert ex <= tol * (x.abs().max().item() + 1e-9), "%s[%s] trunk err %.3e" % (name, dtype, ex)
+    ea = (got_a - want_a).abs().max().item()
+    assert ea <= 1.5 * tol * (want_a.abs().max().item() + 1e-9), "%s[%s] a err %.3e" % (name, dtype, ea)   # a trunk value on a rounding boundary may round the other way
