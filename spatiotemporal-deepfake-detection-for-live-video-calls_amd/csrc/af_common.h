@@ -23,6 +23,12 @@ __device__ __forceinline__ void blds16(unsigned voff, const i32x4& desc, int sof
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(desc), "s"(lds_base), "s"(soff) : "memory");
 }
+// the same with the non-temporal cache policy: for bytes one CU reads once (a residual stream)
+__device__ __forceinline__ void blds16_nt(unsigned voff, const i32x4& desc, int soff, unsigned lds_base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen nt lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(desc), "s"(lds_base), "s"(soff) : "memory");
+}
 // raw buffer descriptor over [base, base + 2 GiB): stride 0, no swizzle, 32-bit data format
 __device__ __forceinline__ i32x4 make_desc(const char* base) {
     const unsigned long long b = (unsigned long long)base;

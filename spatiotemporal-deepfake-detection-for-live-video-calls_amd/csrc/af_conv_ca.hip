@@ -11,9 +11,10 @@
 // added in place (BN, + residual, ReLU, the one rounding), the finished slab is stored to HBM as whole 128-byte rows (the
 // trunk must exist: it is the next residual) and multiplied by the three temporal taps right there.  The `a` conv's
 // 822-MB read disappears: 2.05 GB per pair instead of 2.88.
-// Persistent workgroups, stage stream across tiles (2-slot ring: a-weights of the slab + the image), the b tile of the
-// next tile fetched under the last slab; c weights go global -> registers one stage ahead; BN parameters sit in LDS (a plain
-// global load between the DMA issue and its use would make hipcc wait for the DMA in flight).
+// Persistent workgroups, stage stream across tiles: a-weights of the slab in a 2-slot ring, images in a 3-slot ring with the
+// residual slab fetched TWO stages ahead (Little's law: one 56-KB stage in flight per CU gave 4.1 TB/s), the c weights and
+// the b fragments (K = 64: four 16-byte fragments per lane and tile) go global -> registers a stage / a tile ahead; BN
+// parameters sit in LDS (a plain global load between the DMA issue and its use would make hipcc wait for the DMA in flight).
 #include "af_common.h"
 
 namespace af {
@@ -39,9 +40,9 @@ __global__ __launch_bounds__(512, 2) void conv_ca_kernel(const CAArgs a) {
     static_assert(E::EPC == 8, "16-bit operands only");
     constexpr int BM = 256, TN = 4, TM = 2;
     constexpr int WROWS = 3 * 64;                      // a-weight rows per stage: (dt, channel)
-    constexpr int WPIECES = WROWS / 64;                // DMA pieces per wave
-    constexpr int XPW = 5;                             // image pieces per wave (rows BM + 2P <= 288)
-    constexpr int BPW = BM / 64;                       // b-tile pieces per wave
+    constexpr int WPIECES = WROWS / 64;                // weight DMA pieces per wave
+    constexpr int XPW = 5;                             // image pieces per wave (rows BM + 2P <= 288): 4 or 5 by wave
+    constexpr int WBYTES = WROWS * 128;
 
     extern __shared__ uint4 smem[];
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
@@ -49,10 +50,12 @@ __global__ __launch_bounds__(512, 2) void conv_ca_kernel(const CAArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int frow = lane & 15, fg = lane >> 4;
     const int P = a.P, XR = BM + 2 * P, XP = XR >> 3;
-    const int stage_bytes = (WROWS + XR) * 128;
+    const int img_bytes = XR * 128;
+    // LDS: a-weight ring (2 slots) | image ring (3 slots: the residual slab is fetched TWO stages ahead - one stage in flight
+    // is ~56 KB per CU, which at the loaded HBM latency is 4 TB/s; two are what the stream needs) | BN parameters
     char* sm = reinterpret_cast<char*>(smem);
-    char* btile = sm + 2 * stage_bytes;                // [256 rows][64 ch], swizzled
-    float* bnp = reinterpret_cast<float*>(btile + BM * 128);    // scale_c[C] shift_c[C] scale_a[64] shift_a[64]
+    char* img0 = sm + 2 * WBYTES;
+    float* bnp = reinterpret_cast<float*>(img0 + 3 * img_bytes);     // scale_c[C] shift_c[C] scale_a[64] shift_a[64]
     const int wm = wave;                               // 32-row group of the tile
 
     for (int i = tid; i < a.C; i += 512) { bnp[i] = a.scale_c[i]; bnp[a.C + i] = a.shift_c[i]; }
@@ -77,48 +80,50 @@ __global__ __launch_bounds__(512, 2) void conv_ca_kernel(const CAArgs a) {
         xp[i] = p;
         xoff[i] = (t >= 0 && t < a.T && row < XR) ? (unsigned)((((long long)t * a.HW + p) * a.C) * 2 + chunk * 16) : kOutOfRange;
     }
-    unsigned boff[BPW];
-    int bp[BPW];
-#pragma unroll
-    for (int i = 0; i < BPW; ++i) {
-        const int row = (wave + 8 * i) * 8 + drow;
-        const int t = row / P, p = row % P;
-        bp[i] = p;
-        boff[i] = (unsigned)((((long long)t * a.HW + p) * 64) * 2 + chunk * 16);
-    }
+    const bool five = wave + 8 * (XPW - 1) < XP;                     // this wave issues 5 image pieces per stage (else 4)
     const long long clipx = (long long)a.T * a.HW * a.C * 2, clipb = (long long)a.T * a.HW * 64 * 2;
 
     const int my_tiles = (a.tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     const int total = my_tiles * a.kslabs;
-    int p_tile = blockIdx.x, p_kc = 0;                               // producer cursor
-    auto issue_stage = [&](int slot) {
-        const int n = p_tile / a.chunks, hw0 = (p_tile % a.chunks) * P;
-        const i32x4 xdesc = make_desc(a.res + n * clipx + (long long)hw0 * a.C * 2);
-        const unsigned base = lds0 + slot * stage_bytes + wave * (8 * 128);
-        const int soff = p_kc * 128;
+    // stage index -> (tile, slab)
+    auto stage_tile = [&](int g) { return (int)blockIdx.x + (g / a.kslabs) * (int)gridDim.x; };
+    auto issue_weights = [&](int g) {                                // a-weights of stage g -> weight slot g & 1
+        const unsigned base = lds0 + (g & 1) * WBYTES + wave * (8 * 128);
+        const int soff = (g % a.kslabs) * 128;
 #pragma unroll
         for (int i = 0; i < WPIECES; ++i) blds16(woff[i], wdesc, soff, base + i * (64 * 128));
+    };
+    auto issue_image = [&](int g) {                                  // residual slab of stage g -> image slot g % 3
+        const int tile = stage_tile(g), n = tile / a.chunks, hw0 = (tile % a.chunks) * P;
+        const i32x4 xdesc = make_desc(a.res + n * clipx + (long long)hw0 * a.C * 2);
+        const unsigned base = lds0 + 2 * WBYTES + (g % 3) * img_bytes + wave * (8 * 128);
+        const int soff = (g % a.kslabs) * 128;
 #pragma unroll
         for (int i = 0; i < XPW; ++i)
             if (wave + 8 * i < XP)
-                blds16(hw0 + xp[i] < a.HW ? xoff[i] : kOutOfRange, xdesc, soff, base + WROWS * 128 + i * (64 * 128));
-        if (++p_kc == a.kslabs) { p_kc = 0; p_tile += gridDim.x; }
+                blds16_nt(hw0 + xp[i] < a.HW ? xoff[i] : kOutOfRange, xdesc, soff, base + i * (64 * 128));
     };
-    auto issue_btile = [&](int tile) {
-        const int n = tile / a.chunks, hw0 = (tile % a.chunks) * P;
-        const i32x4 bdesc = make_desc(a.inb + n * clipb + (long long)hw0 * 64 * 2);
-        const unsigned base = lds0 + 2 * stage_bytes + wave * (8 * 128);
-#pragma unroll
-        for (int i = 0; i < BPW; ++i) blds16(hw0 + bp[i] < a.HW ? boff[i] : kOutOfRange, bdesc, 0, base + i * (64 * 128));
-    };
-    // c weights of a stage: 4 channel tiles x 2 k-halves, global -> registers
-    uint4 wcur[TN][2], wnext[TN][2];
+    // c weights of a stage (4 channel tiles x 2 k-halves) and the b fragments of a tile (2 row tiles x 2 k-halves):
+    // global -> registers, a stage / a tile ahead
+    uint4 wcur[TN][2], wnext[TN][2], bcur[TM][2], bnext[TM][2];
     auto load_wc = [&](uint4 (&dst)[TN][2], int kc) {
 #pragma unroll
         for (int i = 0; i < TN; ++i)
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
                 dst[i][kk] = *reinterpret_cast<const uint4*>(a.wc + ((long long)(kc * 64 + i * 16 + frow) * 64 + kk * 32 + fg * 8) * 2);
+    };
+    auto load_b = [&](uint4 (&dst)[TM][2], int tile) {
+        const int n = tile / a.chunks, hw0 = (tile % a.chunks) * P;
+        const char* bb = a.inb + n * clipb + (long long)hw0 * 64 * 2;
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            const int r = wm * 32 + j * 16 + frow, t = r / P, p = r - t * P;
+            const int pc = hw0 + p < a.HW ? p : 0;                    // a pixel beyond the frame: any valid row (its outputs are dropped)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+                dst[j][kk] = *reinterpret_cast<const uint4*>(bb + (((long long)t * a.HW + pc) * 64 + kk * 32 + fg * 8) * 2);
+        }
     };
 
     f32x4 acc[TN][TM];
@@ -129,30 +134,43 @@ __global__ __launch_bounds__(512, 2) void conv_ca_kernel(const CAArgs a) {
 
     if (total > 0) {
         load_wc(wnext, 0);
-        issue_btile(blockIdx.x);
-        issue_stage(0);
+        load_b(bnext, blockIdx.x);
+        issue_weights(0);
+        issue_image(0);
+        if (total > 1) issue_image(1);
     }
     __syncthreads();                                                 // BN parameters visible
     int c_tile = blockIdx.x, c_kc = 0;                               // consumer cursor
     bool after_last = false;
     for (int q = 0; q < total; ++q) {
-        const int slot = q & 1;
-        // stage q (and, at a tile's first slab, its b tile) has landed once at most the younger stores of the previous
-        // iteration are still in flight: 4 trunk-row stores, + 8 `a` output stores behind a tile's last slab
+        // weights(q) and image(q) have landed once only image(q+1)'s pieces (issued right behind weights(q)) and the younger
+        // stores of the previous iteration are still in flight: 4 trunk-row stores, + 8 `a` output stores behind a last slab
         if (q == 0) wait_vmcnt<0>();
-        else if (after_last) wait_vmcnt<12>();
-        else wait_vmcnt<4>();
-        __builtin_amdgcn_s_barrier();                                // ... for everyone; slot ^ 1 is no longer read
+        else if (q + 1 < total) {
+            if (five) { if (after_last) wait_vmcnt<17>(); else wait_vmcnt<9>(); }
+            else      { if (after_last) wait_vmcnt<16>(); else wait_vmcnt<8>(); }
+        } else {
+            if (after_last) wait_vmcnt<12>(); else wait_vmcnt<4>();
+        }
+        __builtin_amdgcn_s_barrier();                                // ... for everyone; weight slot (q+1)&1, image slot (q+2)%3 are free
 #pragma unroll
         for (int i = 0; i < TN; ++i) { wcur[i][0] = wnext[i][0]; wcur[i][1] = wnext[i][1]; }
+        if (c_kc == 0) {
+#pragma unroll
+            for (int j = 0; j < TM; ++j) { bcur[j][0] = bnext[j][0]; bcur[j][1] = bnext[j][1]; }
+        }
+        const bool last = c_kc + 1 == a.kslabs;
         if (q + 1 < total) {
-            load_wc(wnext, c_kc + 1 == a.kslabs ? 0 : c_kc + 1);     // BEFORE the DMA issue: hipcc's wait for these loads must not cover it
+            // plain loads BEFORE the DMA issue: hipcc's wait for them must not cover the DMA
+            load_wc(wnext, last ? 0 : c_kc + 1);
+            if (last) load_b(bnext, c_tile + gridDim.x);
             __builtin_amdgcn_sched_barrier(0);
-            issue_stage(slot ^ 1);
+            issue_weights(q + 1);
+            if (q + 2 < total) issue_image(q + 2);
         }
         __builtin_amdgcn_sched_barrier(0);
         const int n = c_tile / a.chunks, hw0 = (c_tile % a.chunks) * P;
-        char* img = sm + slot * stage_bytes + WROWS * 128;           // image rows: (t + 1) * P + p
+        char* img = img0 + (q % 3) * img_bytes;                      // image rows: (t + 1) * P + p
         // ---- c conv, 64 trunk channels of this slab, in place: image = relu(bn_c(Wc b) + image)
         {
             f32x4 cc[TN][TM];
@@ -160,18 +178,12 @@ __global__ __launch_bounds__(512, 2) void conv_ca_kernel(const CAArgs a) {
             for (int i = 0; i < TN; ++i)
 #pragma unroll
                 for (int j = 0; j < TM; ++j) cc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            const uint4* bs = reinterpret_cast<const uint4*>(btile) + (wm * 32 + frow) * 8;
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                const int c = (kk * 4 + fg) ^ (frow & 7);
-                uint4 bf[TM];
-#pragma unroll
-                for (int j = 0; j < TM; ++j) bf[j] = bs[j * 16 * 8 + c];
+            for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
                 for (int i = 0; i < TN; ++i)
 #pragma unroll
-                    for (int j = 0; j < TM; ++j) Mma<DT>::run(wcur[i][kk], bf[j], cc[i][j]);
-            }
+                    for (int j = 0; j < TM; ++j) Mma<DT>::run(wcur[i][kk], bcur[j][kk], cc[i][j]);
 #pragma unroll
             for (int i = 0; i < TN; ++i) {
                 const f32x4 sc = *reinterpret_cast<const f32x4*>(bnp + c_kc * 64 + i * 16 + fg * 4);
@@ -188,8 +200,6 @@ __global__ __launch_bounds__(512, 2) void conv_ca_kernel(const CAArgs a) {
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                                // the slab of x is complete (raw barrier: the DMA stays in flight)
-        const bool last = c_kc + 1 == a.kslabs;
-        if (last && q + 1 < total) issue_btile(c_tile + gridDim.x);  // the b tile is dead: fetch the next tile's under this slab
         // ---- the finished slab leaves for HBM as whole 128-byte row segments
         {
             char* ox = a.outx + ((long long)n * a.T * a.HW + hw0) * a.C * 2 + c_kc * 128;
@@ -203,8 +213,8 @@ __global__ __launch_bounds__(512, 2) void conv_ca_kernel(const CAArgs a) {
             }
         }
         // ---- a conv: three temporal taps of the slab
-        const uint4* ws = smem + slot * (stage_bytes / 16) + frow * 8;
-        const uint4* xs = smem + slot * (stage_bytes / 16) + WROWS * 8 + (wm * 32 + frow) * 8;
+        const uint4* ws = smem + (q & 1) * (WBYTES / 16) + frow * 8;
+        const uint4* xs = reinterpret_cast<const uint4*>(img) + (wm * 32 + frow) * 8;
 #pragma unroll
         for (int dt = 0; dt < 3; ++dt)
 #pragma unroll
@@ -224,7 +234,7 @@ __global__ __launch_bounds__(512, 2) void conv_ca_kernel(const CAArgs a) {
         if (!last) { ++c_kc; continue; }
 
         // ---- tile finished: BN + ReLU + the one rounding, 8 bytes per lane straight from the accumulators (a 32-KB tile of
-        // a 320-KB tile's traffic: not worth an LDS transposition that would compete with the b tile for space)
+        // a 320-KB tile's traffic: not worth an LDS transposition)
 #pragma unroll
         for (int j = 0; j < TM; ++j) {
             const int r = wm * 32 + j * 16 + frow;                   // tile row = t * P + p
@@ -246,7 +256,7 @@ __global__ __launch_bounds__(512, 2) void conv_ca_kernel(const CAArgs a) {
 
 template <int DT>
 static int launch_ca(const CAArgs& a, int blocks, hipStream_t stream) {
-    const int lds = 2 * (3 * 64 + 256 + 2 * a.P) * 128 + 256 * 128 + (2 * a.C + 128) * 4;
+    const int lds = 2 * 3 * 64 * 128 + 3 * (256 + 2 * a.P) * 128 + (2 * a.C + 128) * 4;
     if (lds > 160 * 1024) return set_error(AF_ERR_ARG, "conv_ca: %d bytes of LDS needed", lds);
     AF_SET_MAX_LDS((&conv_ca_kernel<DT>), 160 * 1024, "conv_ca");
     hipLaunchKernelGGL((conv_ca_kernel<DT>), dim3(blocks), dim3(512), lds, stream, a);
