@@ -110,7 +110,10 @@ def roofline_report(eng, args, line, reps=5):
         if op.kind == _lib.AF_OP_CONV_CA:                # b tile + residual + trunk out + a out + both weights; the trunk is not re-read
             cc_, ca = op.conv, op.conv2
             pos = cc_.n * cc_.to * cc_.ho * cc_.wo
-            eng_bytes[i] = es * (pos * cc_.cin + 2 * pos * cc_.cout + pos * ca.cout + cc_.cout * cc_.cin + ca.cout * ca.cin * 3)
+            # plain block: b tile + residual + trunk out + a out; projection block: b tile + shortcut input + trunk out + a out
+            side = op.conv3.cin if op.in3 else cc_.cout
+            eng_bytes[i] = es * (pos * (cc_.cin + side + cc_.cout + ca.cout) + cc_.cout * (cc_.cin + (op.conv3.cin if op.in3 else 0))
+                                 + ca.cout * ca.cin * 3)
         elif op.kind == _lib.AF_OP_CONV_BC:              # b input + c output + residual + both weights; the b output stays on chip
             cb, cc_ = op.conv, op.conv2
             pos = cb.n * cb.to * cb.ho * cb.wo

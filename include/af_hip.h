@@ -191,12 +191,15 @@ int af_conv3d_bc_bn_act(const af_conv_desc* db, const void* in, const void* wb_p
  * in the time-tiled layout of the 3x1x1 kernel (tile = all T frames of a few pixels: the temporal halo is inside the tile):
  * per 64-channel slab of the trunk the residual is fetched, the c conv's slab is computed and added in LDS, stored once and
  * multiplied by the three temporal taps there - the `a` conv no longer re-reads the trunk from HBM.  dc: 64 -> C channels
- * (C % 64 == 0), residual required, ReLU; da: C -> 64, kernel [3,1,1], pad [1,0,0]; T = 16 or 32; batches with >= 4 tiles per
- * CU (af_conv_ca_fusable says whether a pair qualifies). */
-int af_conv_ca_fusable(const af_conv_desc* dc, const af_conv_desc* da);
-int af_conv3d_ca_bn_act(const af_conv_desc* dc, const void* in_b, const void* wc_packed, const float* scale_c, const float* shift_c,
-                        const void* residual, void* out_x, const af_conv_desc* da, const void* wa_packed, const float* scale_a,
-                        const float* shift_a, void* out_a, void* stream);
+ * (C % 64 == 0), ReLU; da: C -> 64, kernel [3,1,1], pad [1,0,0]; T = 16 or 32; batches with >= 4 tiles per CU
+ * (af_conv_ca_fusable says whether a pair qualifies).  Block 0 of a stage: instead of `residual`, the projection shortcut
+ * (d1: 1x1x1, stride 1, 64 -> C over in1; both weight sets packed with their BN scale, scale_c = ones, shift_c = the summed
+ * shifts - as for af_conv3d_dual_bn_act) is a second K segment of the c conv's accumulator; d1 / in1 / w1_packed are NULL otherwise. */
+int af_conv_ca_fusable(const af_conv_desc* dc, const af_conv_desc* d1, const af_conv_desc* da);
+int af_conv3d_ca_bn_act(const af_conv_desc* dc, const void* in_b, const void* wc_packed, const af_conv_desc* d1, const void* in1,
+                        const void* w1_packed, const float* scale_c, const float* shift_c, const void* residual, void* out_x,
+                        const af_conv_desc* da, const void* wa_packed, const float* scale_a, const float* shift_a, void* out_a,
+                        void* stream);
 
 /* which tile variant af_conv3d_[dual_]bn_act launches for `d` (+ optional `d2`) (>= 0) and its kernel name:
  * lets a profiler attribute per-layer device time and FLOPs to a kernel instantiation (bench.py roofline). */
@@ -351,9 +354,13 @@ typedef struct af_op {
     int64_t workspace_bytes;
     /* HEAD / LINEAR only: optional per-row scores (af_avgpool_fc_scores) */
     float* scores;
-    /* CONV_BC only: BatchNorm of the second (c) conv */
+    /* CONV_BC / CONV_CA: BatchNorm of the second conv */
     const float* scale2;
     const float* shift2;
+    /* CONV_CA of a projection block only: the shortcut segment (NULL in3: plain block with a residual) */
+    af_conv_desc conv3;
+    const void* in3;
+    const void* weight3;
 } af_op;
 
 /* Enqueue ops[0..n) in order on `stream` (AltFreezing: ResNet.forward, video_model_builder.py:561-578). */

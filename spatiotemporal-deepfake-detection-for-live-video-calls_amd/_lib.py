@@ -48,6 +48,7 @@ class Op(C.Structure):
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
         ("scores", C.c_void_p),
         ("scale2", C.c_void_p), ("shift2", C.c_void_p),
+        ("conv3", ConvDesc), ("in3", C.c_void_p), ("weight3", C.c_void_p),
     ]
 
 
@@ -81,8 +82,9 @@ ABI = {
     "af_conv3d_bn_act": (C.c_int, [C.POINTER(ConvDesc)] + [C.c_void_p] * 6 + [C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
     "af_conv3d_dual_bn_act": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_void_p, C.POINTER(ConvDesc)] + [C.c_void_p] * 5
                               + [C.c_int, C.c_void_p]),
-    "af_conv_ca_fusable": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvDesc)]),
-    "af_conv3d_ca_bn_act": (C.c_int, [C.POINTER(ConvDesc)] + [C.c_void_p] * 6 + [C.POINTER(ConvDesc)] + [C.c_void_p] * 5),
+    "af_conv_ca_fusable": (C.c_int, [C.POINTER(ConvDesc)] * 3),
+    "af_conv3d_ca_bn_act": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_void_p, C.POINTER(ConvDesc)] + [C.c_void_p] * 6
+                            + [C.POINTER(ConvDesc)] + [C.c_void_p] * 5),
     "af_conv_bc_fusable": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvDesc)]),
     "af_conv3d_bc_bn_act": (C.c_int, [C.POINTER(ConvDesc)] + [C.c_void_p] * 4 + [C.POINTER(ConvDesc)] + [C.c_void_p] * 5
                             + [C.c_int, C.c_void_p]),

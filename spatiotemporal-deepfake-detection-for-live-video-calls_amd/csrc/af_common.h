@@ -60,9 +60,9 @@ int conv133g_fused_run(const af_conv_desc* db, const void* in, const void* wb, c
                        const af_conv_desc* dc, const void* wc, const float* scale_c, const float* shift_c, const void* residual,
                        void* out, int out_ld, hipStream_t stream);
 // af_conv_ca.hip: c(i) -> a(i+1) across a block boundary of s2 in the time-tiled layout (the trunk slab is produced in LDS)
-bool conv_ca_applies(const af_conv_desc* dc, const af_conv_desc* da);
-int conv_ca_run(const af_conv_desc* dc, const void* inb, const void* wc, const float* scale_c, const float* shift_c,
-                const void* residual, void* outx, const af_conv_desc* da, const void* wa, const float* scale_a,
+bool conv_ca_applies(const af_conv_desc* dc, const af_conv_desc* d1, const af_conv_desc* da);
+int conv_ca_run(const af_conv_desc* dc, const void* inb, const void* wc, const void* in1, const void* w1, const float* scale_c,
+                const float* shift_c, const void* residual, void* outx, const af_conv_desc* da, const void* wa, const float* scale_a,
                 const float* shift_a, void* outa, hipStream_t stream);
 // af_conv_small.hip: direct-gather MFMA path for narrow layers (<= 16 output channels, <= 32 K chunks): SlowFast's Fast pathway
 bool conv_small_applies(const af_conv_desc* d, const af_conv_desc* d2, const void* residual, int out_ld);

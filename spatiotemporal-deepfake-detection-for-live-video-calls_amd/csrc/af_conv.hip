@@ -764,21 +764,26 @@ extern "C" int af_conv3d_bn_act(const af_conv_desc* d, const void* in, const voi
     return conv_common(d, in, w_packed, nullptr, nullptr, nullptr, scale, shift, residual, out, out_ld, workspace, workspace_bytes, stream);
 }
 
-extern "C" int af_conv_ca_fusable(const af_conv_desc* dc, const af_conv_desc* da) { return af::conv_ca_applies(dc, da) ? 1 : 0; }
+extern "C" int af_conv_ca_fusable(const af_conv_desc* dc, const af_conv_desc* d1, const af_conv_desc* da) {
+    return af::conv_ca_applies(dc, d1, da) ? 1 : 0;
+}
 
-extern "C" int af_conv3d_ca_bn_act(const af_conv_desc* dc, const void* in_b, const void* wc_packed, const float* scale_c,
-                                   const float* shift_c, const void* residual, void* out_x, const af_conv_desc* da,
-                                   const void* wa_packed, const float* scale_a, const float* shift_a, void* out_a, void* stream) {
+extern "C" int af_conv3d_ca_bn_act(const af_conv_desc* dc, const void* in_b, const void* wc_packed, const af_conv_desc* d1,
+                                   const void* in1, const void* w1_packed, const float* scale_c, const float* shift_c,
+                                   const void* residual, void* out_x, const af_conv_desc* da, const void* wa_packed,
+                                   const float* scale_a, const float* shift_a, void* out_a, void* stream) {
     using namespace af;
-    AF_REQUIRE(dc && da && in_b && wc_packed && scale_c && shift_c && residual && out_x && wa_packed && scale_a && shift_a && out_a,
-               "conv_ca: null argument");
-    AF_REQUIRE(aligned16(in_b) && aligned16(wc_packed) && aligned16(scale_c) && aligned16(shift_c) && aligned16(residual) &&
-                   aligned16(out_x) && aligned16(wa_packed) && aligned16(scale_a) && aligned16(shift_a) && aligned16(out_a),
+    AF_REQUIRE(dc && da && in_b && wc_packed && scale_c && shift_c && out_x && wa_packed && scale_a && shift_a && out_a, "conv_ca: null argument");
+    AF_REQUIRE((d1 != nullptr) == (in1 != nullptr) && (d1 != nullptr) == (w1_packed != nullptr) && (d1 != nullptr) != (residual != nullptr),
+               "conv_ca: either a residual (plain block) or the projection shortcut (d1, in1, w1: block 0), not both");
+    AF_REQUIRE(aligned16(in_b) && aligned16(wc_packed) && aligned16(in1) && aligned16(w1_packed) && aligned16(scale_c) && aligned16(shift_c) &&
+                   aligned16(residual) && aligned16(out_x) && aligned16(wa_packed) && aligned16(scale_a) && aligned16(shift_a) && aligned16(out_a),
                "conv_ca: buffers must be 16-byte aligned");
     AF_REQUIRE(dc->to == dc->t && dc->ho == dc->h && dc->wo == dc->w && da->to == da->t && da->ho == da->h && da->wo == da->w,
                "conv_ca: both convolutions keep the tensor size");
-    AF_REQUIRE(conv_ca_applies(dc, da), "conv_ca: this (1x1x1 c, 3x1x1 a) pair does not take the fused path (ask af_conv_ca_fusable first)");
-    return conv_ca_run(dc, in_b, wc_packed, scale_c, shift_c, residual, out_x, da, wa_packed, scale_a, shift_a, out_a, (hipStream_t)stream);
+    AF_REQUIRE(conv_ca_applies(dc, d1, da), "conv_ca: this (1x1x1 c, 3x1x1 a) pair does not take the fused path (ask af_conv_ca_fusable first)");
+    return conv_ca_run(dc, in_b, wc_packed, in1, w1_packed, scale_c, shift_c, residual, out_x, da, wa_packed, scale_a, shift_a, out_a,
+                       (hipStream_t)stream);
 }
 
 extern "C" int af_conv_bc_fusable(const af_conv_desc* db, const af_conv_desc* dc) {

@@ -24,7 +24,9 @@ struct CAArgs {
     const char* wc;      // packed [C][64]
     const float* scale_c;
     const float* shift_c;
-    const char* res;     // [N][T][HW][C]
+    const char* res;     // [N][T][HW][C]   (plain blocks)
+    const char* in1;     // [N][T][HW][64]  DUAL: the projection shortcut's input (block 0 of the stage), no residual
+    const char* w1;      // packed [C][64]  DUAL: shortcut weights (both weight sets carry their BN scale, scale_c = ones)
     char* outx;          // [N][T][HW][C]
     const char* wa;      // packed [64][3][C]
     const float* scale_a;
@@ -34,7 +36,9 @@ struct CAArgs {
     int P, chunks, tiles;
 };
 
-template <int DT>
+// DUAL: block 0 of a stage - x = relu(bn_c(c(b)) + bn_1(branch1(x0))) with the 1x1x1 projection shortcut as a second K segment
+// of the same accumulator (no residual tensor: the image rows are written, not updated; their padding frames are zeroed once).
+template <int DT, bool DUAL>
 __global__ __launch_bounds__(512, 2) void conv_ca_kernel(const CAArgs a) {
     typedef Elem<DT> E;
     static_assert(E::EPC == 8, "16-bit operands only");
@@ -54,11 +58,18 @@ __global__ __launch_bounds__(512, 2) void conv_ca_kernel(const CAArgs a) {
     // LDS: a-weight ring (2 slots) | image ring (3 slots: the residual slab is fetched TWO stages ahead - one stage in flight
     // is ~56 KB per CU, which at the loaded HBM latency is 4 TB/s; two are what the stream needs) | BN parameters
     char* sm = reinterpret_cast<char*>(smem);
+    // (DUAL: no residual is fetched, the c conv WRITES the slab: one image buffer; the room goes to the two c weight sets,
+    //  [C][64] each, resident in LDS for the life of the workgroup)
     char* img0 = sm + 2 * WBYTES;
-    float* bnp = reinterpret_cast<float*>(img0 + 3 * img_bytes);     // scale_c[C] shift_c[C] scale_a[64] shift_a[64]
+    char* wlds = img0 + (DUAL ? 1 : 3) * img_bytes;
+    float* bnp = reinterpret_cast<float*>(wlds + (DUAL ? 2 * a.C * 128 : 0));     // scale_c[C] shift_c[C] scale_a[64] shift_a[64]
     const int wm = wave;                               // 32-row group of the tile
 
     for (int i = tid; i < a.C; i += 512) { bnp[i] = a.scale_c[i]; bnp[a.C + i] = a.shift_c[i]; }
+    if (DUAL) {                                        // no residual DMA ever touches the images: zero them (padding frames) once
+        uint4* z = reinterpret_cast<uint4*>(img0);
+        for (int i = tid; i < img_bytes / 16; i += 512) z[i] = uint4{0u, 0u, 0u, 0u};
+    }
     if (tid < 64) { bnp[2 * a.C + tid] = a.scale_a[tid]; bnp[2 * a.C + 64 + tid] = a.shift_a[tid]; }
 
     // ---- producer state
@@ -105,17 +116,18 @@ __global__ __launch_bounds__(512, 2) void conv_ca_kernel(const CAArgs a) {
     };
     // c weights of a stage (4 channel tiles x 2 k-halves) and the b fragments of a tile (2 row tiles x 2 k-halves):
     // global -> registers, a stage / a tile ahead
-    uint4 wcur[TN][2], wnext[TN][2], bcur[TM][2], bnext[TM][2];
-    auto load_wc = [&](uint4 (&dst)[TN][2], int kc) {
+    uint4 wcur[TN][2], bcur[TM][2], x0cur[TM][2];
+    uint4 wnext[TN][2], bnext[TM][2], x0next[TM][2];
+    auto load_wc = [&](uint4 (&dst)[TN][2], const char* wsrc, int kc) {
 #pragma unroll
         for (int i = 0; i < TN; ++i)
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
-                dst[i][kk] = *reinterpret_cast<const uint4*>(a.wc + ((long long)(kc * 64 + i * 16 + frow) * 64 + kk * 32 + fg * 8) * 2);
+                dst[i][kk] = *reinterpret_cast<const uint4*>(wsrc + ((long long)(kc * 64 + i * 16 + frow) * 64 + kk * 32 + fg * 8) * 2);
     };
-    auto load_b = [&](uint4 (&dst)[TM][2], int tile) {
+    auto load_b = [&](uint4 (&dst)[TM][2], const char* bsrc, int tile) {
         const int n = tile / a.chunks, hw0 = (tile % a.chunks) * P;
-        const char* bb = a.inb + n * clipb + (long long)hw0 * 64 * 2;
+        const char* bb = bsrc + n * clipb + (long long)hw0 * 64 * 2;
 #pragma unroll
         for (int j = 0; j < TM; ++j) {
             const int r = wm * 32 + j * 16 + frow, t = r / P, p = r - t * P;
@@ -133,11 +145,22 @@ __global__ __launch_bounds__(512, 2) void conv_ca_kernel(const CAArgs a) {
         for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     if (total > 0) {
-        load_wc(wnext, 0);
-        load_b(bnext, blockIdx.x);
+        if (!DUAL) load_wc(wnext, a.wc, 0);
+        load_b(bnext, a.inb, blockIdx.x);
+        if (DUAL) {
+            load_b(x0next, a.in1, blockIdx.x);
+            const i32x4 d0 = make_desc(a.wc), d1 = make_desc(a.w1);          // both c weight sets -> LDS, rows swizzled like the rings
+            const unsigned off = (unsigned)(drow * 128 + chunk * 16), base = lds0 + (unsigned)(wlds - sm) + wave * (8 * 128);
+            for (int g = 0; g < a.C / 64; ++g) {
+                blds16(off, d0, (g * 64 + wave * 8) * 128, base + g * (64 * 128));
+                blds16(off, d1, (g * 64 + wave * 8) * 128, base + a.C * 128 + g * (64 * 128));
+            }
+        }
         issue_weights(0);
-        issue_image(0);
-        if (total > 1) issue_image(1);
+        if (!DUAL) {
+            issue_image(0);
+            if (total > 1) issue_image(1);
+        }
     }
     __syncthreads();                                                 // BN parameters visible
     int c_tile = blockIdx.x, c_kc = 0;                               // consumer cursor
@@ -146,31 +169,41 @@ __global__ __launch_bounds__(512, 2) void conv_ca_kernel(const CAArgs a) {
         // weights(q) and image(q) have landed once only image(q+1)'s pieces (issued right behind weights(q)) and the younger
         // stores of the previous iteration are still in flight: 4 trunk-row stores, + 8 `a` output stores behind a last slab
         if (q == 0) wait_vmcnt<0>();
-        else if (q + 1 < total) {
+        else if (!DUAL && q + 1 < total) {
             if (five) { if (after_last) wait_vmcnt<17>(); else wait_vmcnt<9>(); }
             else      { if (after_last) wait_vmcnt<16>(); else wait_vmcnt<8>(); }
         } else {
             if (after_last) wait_vmcnt<12>(); else wait_vmcnt<4>();
         }
         __builtin_amdgcn_s_barrier();                                // ... for everyone; weight slot (q+1)&1, image slot (q+2)%3 are free
+        if (!DUAL) {
 #pragma unroll
-        for (int i = 0; i < TN; ++i) { wcur[i][0] = wnext[i][0]; wcur[i][1] = wnext[i][1]; }
+            for (int i = 0; i < TN; ++i) { wcur[i][0] = wnext[i][0]; wcur[i][1] = wnext[i][1]; }
+        }
         if (c_kc == 0) {
 #pragma unroll
-            for (int j = 0; j < TM; ++j) { bcur[j][0] = bnext[j][0]; bcur[j][1] = bnext[j][1]; }
+            for (int j = 0; j < TM; ++j)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    bcur[j][kk] = bnext[j][kk];
+                    if (DUAL) x0cur[j][kk] = x0next[j][kk];
+                }
         }
         const bool last = c_kc + 1 == a.kslabs;
         if (q + 1 < total) {
             // plain loads BEFORE the DMA issue: hipcc's wait for them must not cover the DMA
-            load_wc(wnext, last ? 0 : c_kc + 1);
-            if (last) load_b(bnext, c_tile + gridDim.x);
+            if (!DUAL) load_wc(wnext, a.wc, last ? 0 : c_kc + 1);
+            if (last) {
+                load_b(bnext, a.inb, c_tile + gridDim.x);
+                if (DUAL) load_b(x0next, a.in1, c_tile + gridDim.x);
+            }
             __builtin_amdgcn_sched_barrier(0);
             issue_weights(q + 1);
-            if (q + 2 < total) issue_image(q + 2);
+            if (!DUAL && q + 2 < total) issue_image(q + 2);
         }
         __builtin_amdgcn_sched_barrier(0);
         const int n = c_tile / a.chunks, hw0 = (c_tile % a.chunks) * P;
-        char* img = img0 + (q % 3) * img_bytes;                      // image rows: (t + 1) * P + p
+        char* img = img0 + (DUAL ? 0 : q % 3) * img_bytes;           // image rows: (t + 1) * P + p
         // ---- c conv, 64 trunk channels of this slab, in place: image = relu(bn_c(Wc b) + image)
         {
             f32x4 cc[TN][TM];
@@ -179,11 +212,25 @@ __global__ __launch_bounds__(512, 2) void conv_ca_kernel(const CAArgs a) {
 #pragma unroll
                 for (int j = 0; j < TM; ++j) cc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
+            for (int kk = 0; kk < 2; ++kk) {
+                if (DUAL) {                                          // both weight slabs from their LDS images
+                    const uint4* wl = reinterpret_cast<const uint4*>(wlds) + (c_kc * 64 + frow) * 8 + ((kk * 4 + fg) ^ (frow & 7));
 #pragma unroll
-                for (int i = 0; i < TN; ++i)
+                    for (int i = 0; i < TN; ++i) {
+                        const uint4 w0 = wl[i * 16 * 8], w1 = wl[a.C * 8 + i * 16 * 8];
 #pragma unroll
-                    for (int j = 0; j < TM; ++j) Mma<DT>::run(wcur[i][kk], bcur[j][kk], cc[i][j]);
+                        for (int j = 0; j < TM; ++j) {
+                            Mma<DT>::run(w0, bcur[j][kk], cc[i][j]);
+                            Mma<DT>::run(w1, x0cur[j][kk], cc[i][j]);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < TN; ++i)
+#pragma unroll
+                        for (int j = 0; j < TM; ++j) Mma<DT>::run(wcur[i][kk], bcur[j][kk], cc[i][j]);
+                }
+            }
 #pragma unroll
             for (int i = 0; i < TN; ++i) {
                 const f32x4 sc = *reinterpret_cast<const f32x4*>(bnp + c_kc * 64 + i * 16 + fg * 4);
@@ -192,7 +239,8 @@ __global__ __launch_bounds__(512, 2) void conv_ca_kernel(const CAArgs a) {
                 for (int j = 0; j < TM; ++j) {
                     const int R = P + wm * 32 + j * 16 + frow;       // image row of this position (R & 7 == frow & 7: P % 8 == 0)
                     char* cell = img + R * 128 + (((i * 2 + (fg >> 1)) ^ (frow & 7)) << 4) + (fg & 1) * 8;
-                    f32x4 v = cc[i][j] * sc + sf + Vec4<DT>::load(cell);
+                    f32x4 v = cc[i][j] * sc + sf;
+                    if (!DUAL) v += Vec4<DT>::load(cell);
                     v[0] = relu_f(v[0]); v[1] = relu_f(v[1]); v[2] = relu_f(v[2]); v[3] = relu_f(v[3]);
                     Vec4<DT>::store(cell, v);
                 }
@@ -254,18 +302,24 @@ __global__ __launch_bounds__(512, 2) void conv_ca_kernel(const CAArgs a) {
     }
 }
 
-template <int DT>
+template <int DT, bool DUAL>
 static int launch_ca(const CAArgs& a, int blocks, hipStream_t stream) {
-    const int lds = 2 * 3 * 64 * 128 + 3 * (256 + 2 * a.P) * 128 + (2 * a.C + 128) * 4;
+    const int lds = 2 * 3 * 64 * 128 + (DUAL ? (256 + 2 * a.P) * 128 + 2 * a.C * 128 : 3 * (256 + 2 * a.P) * 128) + (2 * a.C + 128) * 4;
     if (lds > 160 * 1024) return set_error(AF_ERR_ARG, "conv_ca: %d bytes of LDS needed", lds);
-    AF_SET_MAX_LDS((&conv_ca_kernel<DT>), 160 * 1024, "conv_ca");
-    hipLaunchKernelGGL((conv_ca_kernel<DT>), dim3(blocks), dim3(512), lds, stream, a);
+    AF_SET_MAX_LDS((&conv_ca_kernel<DT, DUAL>), 160 * 1024, "conv_ca");
+    hipLaunchKernelGGL((conv_ca_kernel<DT, DUAL>), dim3(blocks), dim3(512), lds, stream, a);
     AF_CHECK_LAUNCH("conv_ca_kernel");
     return AF_OK;
 }
 
 // dc: the 1x1x1 `c` conv (64 -> C, with residual + ReLU), da: the 3x1x1 `a` conv of the next block (C -> 64) over its output
-bool conv_ca_applies(const af_conv_desc* dc, const af_conv_desc* da) {
+// d1 (optional): the projection shortcut of block 0 - a 1x1x1 stride-1 conv from 64 channels onto the same positions
+bool conv_ca_applies(const af_conv_desc* dc, const af_conv_desc* d1, const af_conv_desc* da) {
+    if (d1) {
+        if (d1->dtype != dc->dtype || d1->tpool || d1->kt != 1 || d1->kh != 1 || d1->kw != 1 || d1->st != 1 || d1->sh != 1 || d1->sw != 1) return false;
+        if (d1->pt || d1->ph || d1->pw || d1->cin != 64 || d1->cout != dc->cout) return false;
+        if (d1->n != dc->n || d1->t != dc->t || d1->h != dc->h || d1->w != dc->w) return false;
+    }
     if (!dc || !da || dc->dtype == AF_F32 || da->dtype != dc->dtype || dc->tpool || da->tpool) return false;
     if (dc->kt != 1 || dc->kh != 1 || dc->kw != 1 || dc->st != 1 || dc->sh != 1 || dc->sw != 1 || dc->pt || dc->ph || dc->pw) return false;
     if (da->kt != 3 || da->kh != 1 || da->kw != 1 || da->st != 1 || da->sh != 1 || da->sw != 1 || da->pt != 1 || da->ph || da->pw) return false;
@@ -280,17 +334,19 @@ bool conv_ca_applies(const af_conv_desc* dc, const af_conv_desc* da) {
     return tiles >= 4LL * device_cus() && tiles < (1LL << 31);
 }
 
-int conv_ca_run(const af_conv_desc* dc, const void* inb, const void* wc, const float* scale_c, const float* shift_c,
-                const void* residual, void* outx, const af_conv_desc* da, const void* wa, const float* scale_a,
+int conv_ca_run(const af_conv_desc* dc, const void* inb, const void* wc, const void* in1, const void* w1, const float* scale_c,
+                const float* shift_c, const void* residual, void* outx, const af_conv_desc* da, const void* wa, const float* scale_a,
                 const float* shift_a, void* outa, hipStream_t stream) {
     CAArgs a;
     a.inb = (const char*)inb; a.wc = (const char*)wc; a.scale_c = scale_c; a.shift_c = shift_c; a.res = (const char*)residual;
+    a.in1 = (const char*)in1; a.w1 = (const char*)w1;
     a.outx = (char*)outx; a.wa = (const char*)wa; a.scale_a = scale_a; a.shift_a = shift_a; a.outa = (char*)outa;
     a.T = dc->t; a.HW = dc->h * dc->w; a.C = dc->cout; a.kslabs = dc->cout / 64;
     a.P = 256 / dc->t; a.chunks = (a.HW + a.P - 1) / a.P; a.tiles = dc->n * a.chunks;
     const int cus = device_cus();
     const int blocks = a.tiles < cus ? a.tiles : cus;
-    return dc->dtype == AF_BF16 ? launch_ca<AF_BF16>(a, blocks, stream) : launch_ca<AF_F16>(a, blocks, stream);
+    if (in1) return dc->dtype == AF_BF16 ? launch_ca<AF_BF16, true>(a, blocks, stream) : launch_ca<AF_F16, true>(a, blocks, stream);
+    return dc->dtype == AF_BF16 ? launch_ca<AF_BF16, false>(a, blocks, stream) : launch_ca<AF_F16, false>(a, blocks, stream);
 }
 
 }  // namespace af

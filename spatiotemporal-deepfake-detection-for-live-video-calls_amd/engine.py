@@ -187,14 +187,17 @@ class _Plan:
     def add(self, **e):
         self.entries.append(e)
 
-    def ca_fusable(self, c: ConvSpec, a_next: ConvSpec, db, dc) -> bool:
-        """does the library run this block's c conv (+ residual + ReLU) and the NEXT block's a conv as one launch (af_conv3d_ca_bn_act)?"""
+    def ca_fusable(self, c: ConvSpec, a_next: ConvSpec, db, dc, branch1: ConvSpec = None, d_in=None) -> bool:
+        """does the library run this block's c conv (+ residual or projection shortcut, + ReLU) and the NEXT block's a conv as one
+        launch (af_conv3d_ca_bn_act)?"""
         if self.code is None or os.environ.get("AF_FUSE_CA", "1") != "1":
             return False
-        d1, d2 = _lib.ConvDesc(), _lib.ConvDesc()
+        d1, d2, d3 = _lib.ConvDesc(), _lib.ConvDesc(), _lib.ConvDesc()
         _fill_conv_desc(d1, self.batch, self.code, c, db, dc, True)
         _fill_conv_desc(d2, self.batch, self.code, a_next, dc, a_next.out_dims(*dc), True)
-        return bool(lib.af_conv_ca_fusable(C.byref(d1), C.byref(d2)))
+        if branch1 is not None:
+            _fill_conv_desc(d3, self.batch, self.code, branch1, d_in, dc, True)
+        return bool(lib.af_conv_ca_fusable(C.byref(d1), C.byref(d3) if branch1 is not None else None, C.byref(d2)))
 
     def stage(self, stage, d, cur, nxt, a_buf, b_buf, last_ld=None, tpool_last=False):
         """One pathway's ResStage.  ``last_ld``: row stride of the stage's final output (room for the lateral's
@@ -255,7 +258,15 @@ class _Plan:
             if blk.branch1 is not None and blk.branch1.pool_after_bn is None:
                 # c conv + projection shortcut in one launch; no shortcut tensor
                 assert blk.branch1.out_dims(*d) == dc
-                self.add(kind="dual", cv=blk.c, cv2=blk.branch1, din=db, din2=d, dout=dc, src=c_src, src2=cur, dst=nxt, ld=ld)
+                if (not last and ld == blk.c.cout and stage.blocks[bi + 1].a.pool_after_bn is None
+                        and self.ca_fusable(blk.c, stage.blocks[bi + 1].a, db, dc, blk.branch1, d)):
+                    # ... and the next block's a conv behind them (s2): the trunk slab never comes back from HBM
+                    nxa = stage.blocks[bi + 1].a
+                    self.add(kind="ca", cv=blk.c, cv2=nxa, cv3=blk.branch1, din=db, din3=d, dout=dc, src=c_src, src3=cur, dst=nxt, dst2=a_buf)
+                    self.need(a_buf, nxa.out_dims(*dc), nxa.cout)
+                    a_done = True
+                else:
+                    self.add(kind="dual", cv=blk.c, cv2=blk.branch1, din=db, din2=d, dout=dc, src=c_src, src2=cur, dst=nxt, ld=ld)
             elif (not last and not tp and res_src == cur and ld == blk.c.cout and stage.blocks[bi + 1].a.pool_after_bn is None
                   and self.ca_fusable(blk.c, stage.blocks[bi + 1].a, db, dc)):
                 # c + residual + ReLU of this block and the a conv of the next one in one launch (s2): the trunk slab is
@@ -471,15 +482,25 @@ class Engine:
                 op.kind, op.tag = _lib.AF_OP_CONV_CA, TAG_CONV_CA
                 fill_conv(op.conv, cvc, e["din"], e["dout"], True)
                 fill_conv(op.conv2, cva, e["dout"], cva.out_dims(*e["dout"]), True)
-                op.weight, op.scale, op.shift = (weights.w[cvc.conv].data_ptr(), weights.scale[cvc.conv].data_ptr(),
-                                                 weights.shift[cvc.conv].data_ptr())
                 op.weight2, op.scale2, op.shift2 = (weights.w[cva.conv].data_ptr(), weights.scale[cva.conv].data_ptr(),
                                                     weights.shift[cva.conv].data_ptr())
-                op.residual = self.buf[e["res"]].data_ptr()
+                macs = cvc.macs(*e["din"]) + cva.macs(*e["dout"])
+                if e.get("cv3") is not None:                 # projection block: folded weights, scale = ones, summed shifts
+                    cv1 = e["cv3"]
+                    fill_conv(op.conv3, cv1, e["din3"], e["dout"], True)
+                    op.weight, op.weight3 = weights.w_folded[cvc.conv].data_ptr(), weights.w_folded[cv1.conv].data_ptr()
+                    op.in3 = self.buf[e["src3"]].data_ptr()
+                    op.scale, op.shift = weights.ones[cvc.conv].data_ptr(), weights.shift_sum[cvc.conv].data_ptr()
+                    op.residual = None
+                    macs += cv1.macs(*e["din3"])
+                else:
+                    op.weight, op.scale, op.shift = (weights.w[cvc.conv].data_ptr(), weights.scale[cvc.conv].data_ptr(),
+                                                     weights.shift[cvc.conv].data_ptr())
+                    op.residual = self.buf[e["res"]].data_ptr()
                 op.aux = self.buf[e["dst2"]].data_ptr()
                 op.out_ld = cvc.cout
-                self.op_names.append(cvc.conv + "->" + cva.conv.split("resnet.")[-1])
-                self.op_macs.append(batch * (cvc.macs(*e["din"]) + cva.macs(*e["dout"])))
+                self.op_names.append(cvc.conv + ("+branch1" if e.get("cv3") is not None else "") + "->" + cva.conv.split("resnet.")[-1])
+                self.op_macs.append(batch * macs)
             elif kind == "bc":
                 cvb, cvc = e["cv"], e["cv2"]
                 op.kind, op.tag = _lib.AF_OP_CONV_BC, TAG_CONV_BC

@@ -110,8 +110,9 @@ def conv_bc(x_ndhwc, wb_oidhw, bn_b, wc_oidhw, bn_c, residual, dtype):
     return out
 
 
-def conv_ca(b_ndhwc, wc_oidhw, bn_c, res_ndhwc, wa_oidhw, bn_a, dtype):
+def conv_ca(b_ndhwc, wc_oidhw, bn_c, res_ndhwc, wa_oidhw, bn_a, dtype, x0_ndhwc=None, w1_oidhw=None, bn_1=None):
     """x = relu(bn_c(conv1x1x1(b)) + res), a_out = relu(bn_a(conv3x1x1(x))) as one af_conv3d_ca_bn_act launch -> (x, a_out);
+    with x0 / w1 / bn_1 (a projection block) x = relu(bn_c(c(b)) + bn_1(conv1x1x1_1(x0))) and res must be None.
     None if the library does not fuse this pair (af_conv_ca_fusable)."""
     L = lib()
     code = L.DTYPE_CODES[dtype]
@@ -124,13 +125,25 @@ def conv_ca(b_ndhwc, wc_oidhw, bn_c, res_ndhwc, wa_oidhw, bn_a, dtype):
     da.n, da.t, da.h, da.w, da.cin, da.cout = n, t, h, w, ctrunk, cout_a
     da.kt, da.kh, da.kw, da.st, da.sh, da.sw, da.pt, da.ph, da.pw = 3, 1, 1, 1, 1, 1, 1, 0, 0
     da.to, da.ho, da.wo, da.relu, da.dtype = t, h, w, 1, code
-    if not L.lib.af_conv_ca_fusable(C.byref(dc), C.byref(da)):
+    d1 = None
+    if x0_ndhwc is not None:
+        d1 = L.ConvDesc()
+        d1.n, d1.t, d1.h, d1.w, d1.cin, d1.cout = n, t, h, w, x0_ndhwc.shape[-1], ctrunk
+        d1.kt = d1.kh = d1.kw = d1.st = d1.sh = d1.sw = 1
+        d1.to, d1.ho, d1.wo, d1.relu, d1.dtype = t, h, w, 1, code
+    if not L.lib.af_conv_ca_fusable(C.byref(dc), None if d1 is None else C.byref(d1), C.byref(da)):
         return None
-    pc, pa = _pack_plain(wc_oidhw, dtype), _pack_plain(wa_oidhw, dtype)
+    pa = _pack_plain(wa_oidhw, dtype)
     x = torch.empty((n, t, h, w, ctrunk), dtype=TORCH_DT[dtype], device="cuda")
     a_out = torch.empty((n, t, h, w, cout_a), dtype=TORCH_DT[dtype], device="cuda")
-    L.check(L.lib.af_conv3d_ca_bn_act(C.byref(dc), _p(b_ndhwc), _p(pc), _p(bn_c[0]), _p(bn_c[1]), _p(res_ndhwc), _p(x), C.byref(da),
-                                      _p(pa), _p(bn_a[0]), _p(bn_a[1]), _p(a_out), _stream()), "conv3d_ca_bn_act")
+    if d1 is None:
+        pc, p1, sc, sf = _pack_plain(wc_oidhw, dtype), None, bn_c[0], bn_c[1]
+    else:           # both weight sets carry their BN scale, scale = ones, shift = the summed shifts (as the engine does)
+        pc, p1 = _pack_scaled(wc_oidhw, bn_c[0], dtype), _pack_scaled(w1_oidhw, bn_1[0], dtype)
+        sc, sf = torch.ones(L.lib.af_padded_channels(ctrunk), device="cuda"), (bn_c[1] + bn_1[1]).contiguous()
+    L.check(L.lib.af_conv3d_ca_bn_act(C.byref(dc), _p(b_ndhwc), _p(pc), None if d1 is None else C.byref(d1), _p(x0_ndhwc), _p(p1), _p(sc),
+                                      _p(sf), _p(res_ndhwc), _p(x), C.byref(da), _p(pa), _p(bn_a[0]), _p(bn_a[1]), _p(a_out), _stream()),
+            "conv3d_ca_bn_act")
     torch.cuda.current_stream().synchronize()
     return x, a_out
 

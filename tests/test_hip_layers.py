@@ -508,3 +508,34 @@ def test_fused_c_a_vs_oracle(name, ctrunk, dims, dtype):
     assert ex <= tol * (x.abs().max().item() + 1e-9), "%s[%s] trunk err %.3e" % (name, dtype, ex)
     ea = (got_a - want_a).abs().max().item()
     assert ea <= 1.5 * tol * (want_a.abs().max().item() + 1e-9), "%s[%s] a err %.3e" % (name, dtype, ea)   # a trunk value on a rounding boundary may round the other way
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+def test_fused_c_shortcut_a_vs_oracle(dtype):
+    """the projection-block form of af_conv3d_ca_bn_act: x = relu(bn_c(c(b)) + bn_1(branch1(x0))), a_out = relu(bn_a(a3x1x1(x))) -
+    block 0 of s2 and the first conv of block 1 in one launch.  The BN scales are folded into the 16-bit weights there (two convs
+    share an accumulator), so the oracle folds them the same way before rounding."""
+    name, ctrunk, (n, t, h, w) = "s2_res0_T32", 256, (2, 32, 64, 66)
+    seed = 6000 + sum(map(ord, name))
+    lay = [("c.weight", (ctrunk, 64, 1, 1, 1), "float32"), ("b1.weight", (ctrunk, 64, 1, 1, 1), "float32"),
+           ("a.weight", (64, ctrunk, 3, 1, 1), "float32")]
+    for p_, ch in (("c_bn", ctrunk), ("b1_bn", ctrunk), ("a_bn", 64)):
+        lay += [(p_ + s_, (ch,), "float32") for s_ in (".weight", ".bias", ".running_mean", ".running_var")]
+    sd = synth.fill_layout(lay, seed)
+    tdt = hh.TORCH_DT[dtype]
+    b = synth.synthetic_tensor((n, 64, t, h, w), seed).to(tdt).float()
+    x0 = synth.synthetic_tensor((n, 64, t, h, w), seed + 1).to(tdt).float()
+    sd["a.weight"] = sd["a.weight"].to(tdt).float()
+    bn_c, bn_1 = hh.fold_bn(sd, "c_bn"), hh.fold_bn(sd, "b1_bn")
+    fold = lambda wk, bn: (sd[wk] * bn[0].cpu()[:ctrunk].view(-1, 1, 1, 1, 1)).to(tdt).double()      # scale folded in fp32, rounded once
+    x = F.conv3d(b.double(), fold("c.weight", bn_c)) + F.conv3d(x0.double(), fold("b1.weight", bn_1))
+    x = F.relu(x + (bn_c[1] + bn_1[1]).cpu()[:ctrunk].double().view(1, -1, 1, 1, 1))
+    sd64 = {k: v.double() for k, v in sd.items()}
+    want_a = oracle.conv_bn_act(x.to(tdt).double(), sd64["a.weight"], sd64, "a_bn", (1, 1, 1), (1, 0, 0), True)
+    out = hh.conv_ca(hh.to_ndhwc(b, dtype), sd["c.weight"], bn_c, None, sd["a.weight"], hh.fold_bn(sd, "a_bn"), dtype,
+                     x0_ndhwc=hh.to_ndhwc(x0, dtype), w1_oidhw=sd["b1.weight"], bn_1=bn_1)
+    assert out is not None, "the library should fuse this pair"
+    got_x, got_a = hh.to_ncdhw(out[0]).double(), hh.to_ncdhw(out[1]).double()
+    tol = {"f16": 1.5e-3, "bf16": 1.2e-2}[dtype]
+    assert (got_x - x).abs().max().item() <= tol * (x.abs().max().item() + 1e-9)
+    assert (got_a - want_a).abs().max().item() <= 1.5 * tol * (want_a.abs().max().item() + 1e-9)
