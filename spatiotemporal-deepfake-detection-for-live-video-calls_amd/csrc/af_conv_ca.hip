@@ -329,7 +329,10 @@ bool conv_ca_applies(const af_conv_desc* dc, const af_conv_desc* d1, const af_co
     const long long hw = (long long)dc->h * dc->w;
     if ((long long)dc->t * hw * dc->cout * 2 >= (1LL << 31)) return false;     // 32-bit offsets inside a clip
     const int p = 256 / dc->t;
-    const long long tiles = (long long)dc->n * ((hw + p - 1) / p);
+    // whole tiles only: the kernel's counted s_waitcnt vmcnt assume that every wave issues every store of an iteration; a
+    // ragged last chunk could mask ALL lanes of a wave's store, hipcc would branch around it and the count would be off
+    if (hw % p != 0) return false;
+    const long long tiles = (long long)dc->n * (hw / p);
     // persistent stream: pays with several tiles per workgroup (small batches keep the two launches)
     return tiles >= 4LL * device_cus() && tiles < (1LL << 31);
 }
