@@ -164,17 +164,13 @@ __global__ __launch_bounds__(512, 2) void conv_ca_kernel(const CAArgs a) {
     }
     __syncthreads();                                                 // BN parameters visible
     int c_tile = blockIdx.x, c_kc = 0;                               // consumer cursor
-    bool after_last = false;
     for (int q = 0; q < total; ++q) {
-        // weights(q) and image(q) have landed once only image(q+1)'s pieces (issued right behind weights(q)) and the younger
-        // stores of the previous iteration are still in flight: 4 trunk-row stores, + 8 `a` output stores behind a last slab
+        // weights(q) and image(q) have landed once only image(q+1)'s pieces (issued right behind weights(q)) and the 4 trunk-row
+        // stores of the previous iteration are still in flight (the 8 `a` output stores behind a tile's last slab are waited for:
+        // once per tile, and the count does not depend on how hipcc emits them)
         if (q == 0) wait_vmcnt<0>();
-        else if (!DUAL && q + 1 < total) {
-            if (five) { if (after_last) wait_vmcnt<17>(); else wait_vmcnt<9>(); }
-            else      { if (after_last) wait_vmcnt<16>(); else wait_vmcnt<8>(); }
-        } else {
-            if (after_last) wait_vmcnt<12>(); else wait_vmcnt<4>();
-        }
+        else if (!DUAL && q + 1 < total) { if (five) wait_vmcnt<9>(); else wait_vmcnt<8>(); }
+        else wait_vmcnt<4>();
         __builtin_amdgcn_s_barrier();                                // ... for everyone; weight slot (q+1)&1, image slot (q+2)%3 are free
         if (!DUAL) {
 #pragma unroll
@@ -278,7 +274,6 @@ __global__ __launch_bounds__(512, 2) void conv_ca_kernel(const CAArgs a) {
 #pragma unroll
                     for (int j = 0; j < TM; ++j) Mma<DT>::run(af[i], bf[j], acc[i][j]);
             }
-        after_last = last;
         if (!last) { ++c_kc; continue; }
 
         // ---- tile finished: BN + ReLU + the one rounding, 8 bytes per lane straight from the accumulators (a 32-KB tile of
