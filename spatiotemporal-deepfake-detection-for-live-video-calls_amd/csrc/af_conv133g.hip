@@ -17,8 +17,6 @@
 //   * at B = 16 the 256 frames of s4 are exactly one unit per CU, the 512 half-frames of s3 exactly two rounds.
 #include "af_common.h"
 
-#include <stdlib.h>
-
 namespace af {
 
 struct C133GArgs {
@@ -343,8 +341,7 @@ static int conv133g_rows(const af_conv_desc* d) {
     if (prows > 512 || 2 * prows * 128 + 2 * d->cout * 128 > 160 * 1024) return 0;
     // worth it when the units fill the chip and most of a unit's positions are real
     const long long units = (long long)d->n * d->t * upf;
-    static const int min_units = [] { const char* e = getenv("AF_C133G_MIN_UNITS"); return e ? atoi(e) : 192; }();
-    if (units < min_units || units > 0x7fffffffLL) return 0;
+    if (units < 192 || units > 0x7fffffffLL) return 0;
     if ((double)d->h * d->w / ((double)upf * mpad) < 0.6) return 0;
     if ((long long)(d->h + 2) * d->w * d->cin * 2 >= (1LL << 31)) return 0;
     return r;
