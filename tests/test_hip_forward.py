@@ -368,3 +368,26 @@ def test_two_stream_mode_matches_single_stream(weights0):
     assert out["scores"].shape == (16,) and out["pooled"].shape == (16, 2048)
     assert torch.allclose(out["scores"].cpu(), torch.sigmoid(y), atol=1e-6)
     assert y17.shape == (17,) and (y17[:16] - want).abs().max().item() <= LOGIT_TOL["f16"] and abs(float(y17[16] - want[0])) <= LOGIT_TOL["f16"]
+
+
+@pytest.mark.parametrize("batch", [3, 5, 12, 13])
+def test_kernel_selection_thresholds_across_batch_sizes(weights0, batch):
+    """The engine picks kernels by batch (conv_ca from 3 clips, conv133g for s3 from 6 and for s4 from 12, split-K below, the
+    persistent streams from 4 tiles per CU ...): the f16 engine at batch sizes around those thresholds against the exact-fp32
+    engine on the same clips (itself pinned to the reference elsewhere in this file)."""
+    u8 = synth.synthetic_clips_u8(batch, seed=100 + batch, kind="smooth").cuda()
+    out = {}
+    for dtype in ("f32", "f16"):
+        clf = Classifier(precision=dtype)
+        clf.network.load_state_dict(weights0)
+        clf = clf.cuda().eval()
+        with torch.inference_mode():
+            out[dtype] = clf.network.forward_clips_u8(u8)["final_output"].cpu().flatten()
+        names = clf.network._engines[(dtype, batch, (32, 224, 224))].op_names
+        if dtype == "f16":
+            assert any("->" in n for n in names) == (batch >= 3), names       # c(i) -> a(i+1) fused in s2
+        del clf
+        torch.cuda.empty_cache()
+    err = (out["f16"] - out["f32"]).abs().max().item()
+    print("B=%d f16 vs f32 engine: max|d| %.3e" % (batch, err))
+    assert err <= LOGIT_TOL["f16"], (batch, err)
