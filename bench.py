@@ -104,7 +104,7 @@ def roofline_report(eng, args, line, reps=5):
             acc = [a + m for a, m in zip(acc, eng.run_timed())]
     ms = [a / reps for a in acc]
     es = 4 if args.dtype == "f32" else 2
-    per_kernel, per_class, eng_bytes, kernel_ops, variants = {}, {}, {}, {}, {}
+    per_kernel, per_class, eng_bytes, kernel_ops, variants, op_kernel = {}, {}, {}, {}, {}, {}
     for i in range(eng.n_ops):
         op = eng.ops[i]
         if op.kind == _lib.AF_OP_CONV_CA:                # b tile + residual + trunk out + a out + both weights; the trunk is not re-read
@@ -146,6 +146,7 @@ def roofline_report(eng, args, line, reps=5):
                      _lib.AF_OP_TSTEM: "tstem_kernel"}[op.kind]
         else:
             continue
+        op_kernel[i] = kname
         fam = kernel_family(kname)
         k = per_kernel.setdefault(fam, {"ms": 0.0, "macs": 0, "launches": 0})
         k["ms"] += ms[i]; k["macs"] += eng.op_macs[i]; k["launches"] += 1
@@ -157,6 +158,8 @@ def roofline_report(eng, args, line, reps=5):
         for i in range(eng.n_ops):
             op = eng.ops[i]
             row = {"i": i, "name": eng.op_names[i], "class": TAG_NAMES[op.tag], "ms": round(ms[i], 4)}
+            if i in op_kernel:
+                row["kernel"] = op_kernel[i]
             if i in eng_bytes:
                 cd = op.conv
                 row.update({"M": cd.n * cd.to * cd.ho * cd.wo, "N": op.conv2.cout if op.kind == _lib.AF_OP_CONV_BC else cd.cout,
