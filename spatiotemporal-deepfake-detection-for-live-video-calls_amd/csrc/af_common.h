@@ -29,6 +29,15 @@ __device__ __forceinline__ void blds16_nt(unsigned voff, const i32x4& desc, int 
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen nt lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(desc), "s"(lds_base), "s"(soff) : "memory");
 }
+// A plain 16-byte buffer load that hipcc does NOT count: for register prefetch several tiles ahead.  (For a counted load the
+// compiler must assume that nothing younger is in the queue when the value is finally used - the stores and loads issued since
+// are conditional for it - and emits s_waitcnt vmcnt(0..3), which drains the LDS-DMA issued behind it as well.)  The caller
+// waits with its own counted s_waitcnt vmcnt and passes the registers through an empty asm ("+v") before the first use.
+__device__ __forceinline__ u32x4 bload16_nt_uncounted(unsigned voff, const i32x4& desc, int soff) {
+    u32x4 r;
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen nt" : "=v"(r) : "v"(voff), "s"(desc), "s"(soff) : "memory");
+    return r;
+}
 // raw buffer descriptor over [base, base + 2 GiB): stride 0, no swizzle, 32-bit data format
 __device__ __forceinline__ i32x4 make_desc(const char* base) {
     const unsigned long long b = (unsigned long long)base;

@@ -8,9 +8,13 @@
 // waits a full memory latency for its operands, a second one for the residual inside the epilogue, and re-fetches
 // the weights (twice the bytes of the activations it multiplies) from L2.  Here
 //   * workgroups are persistent (one per CU) and every wave keeps its 64 output channels x K of WEIGHTS IN REGISTERS;
-//   * a tile is 128 positions; its activations arrive by LDS-DMA into a 2-slot ring and its residual rows by plain
-//     16-byte loads into registers, both issued ONE TILE AHEAD: while tile q is multiplied, transposed and stored,
-//     ~100-150 KB of loads for tile q+1 are in flight per CU, which is what the HBM stream needs (Little's law);
+//   * a tile is 128 positions (K = 64) or 64 (K = 128 / 256); its activations arrive by LDS-DMA into a ring of 2 / 4 slots and
+//     its residual rows by 16-byte loads into registers, both issued ONE / THREE TILES AHEAD: while tile q is multiplied,
+//     transposed and stored, ~100-150 KB of loads for the next tiles are in flight per CU, which is what the HBM stream
+//     needs (Little's law).  Short tiles + a deeper ring keep that amount in flight CONTINUOUSLY (a 128-position tile
+//     of K = 256 issued 128 KB at its start, which had landed half-way through its 6 us of MFMA + epilogue: by ablation
+//     memory alone 50 us, compute alone 39 us, together 68 us; now 59 us).  All waits are counted s_waitcnt vmcnt: the
+//     residual loads are issued through inline asm so that hipcc does not count them (bload16_nt_uncounted, af_common.h);
 //   * the epilogue is the usual per-wave patch: fp32 accumulators -> LDS -> whole 128-byte row segments with
 //     BN, residual, ReLU, the frame-pair max and the one rounding applied on the way out.
 // 8 waves = 4 channel groups x 2 position halves, wave tile 64 channels x 64 positions.
@@ -37,19 +41,36 @@ struct C111Args {
     int tiles;           // position tiles
 };
 
+// s_waitcnt vmcnt(nl * NL + ns * NS) for uniform run-time nl in [0, D-1], ns in [0, D] (the immediate is a compile-time constant)
+template <int NL, int NS, int D, int A = 0, int B = 0>
+__device__ __forceinline__ void wait_counted(int nl, int ns) {
+    if constexpr (A <= D - 1 && B <= D) {
+        if (nl == A && ns == B) { wait_vmcnt<A * NL + B * NS>(); return; }
+        if constexpr (B < D) wait_counted<NL, NS, D, A, B + 1>(nl, ns);
+        else wait_counted<NL, NS, D, A + 1, 0>(nl, ns);
+    } else {
+        wait_vmcnt<0>();
+    }
+}
+
 // WC = output channels per wave: 64 (4 channel groups x 2 position halves) or, for K = 256 where 64 channels of
 // weights would not fit the registers next to two residual sets, 32 (8 channel groups, every wave all 128 positions).
-template <int DT, int KS1, int KS2, bool TPOOL, bool RES, int WC>
+// BM = positions per tile, NSLOT = slots of the activation ring = residual register sets: tile q + NSLOT - 1 is fetched while
+// tile q is multiplied (NSLOT = 2: one tile ahead, the original pipeline; deeper for the short tiles of K = 256).
+template <int DT, int KS1, int KS2, bool TPOOL, bool RES, int WC, int BM = 128, int NSLOT = 2>
 __global__ __launch_bounds__(512, 1) void conv111_kernel(const C111Args a) {
     typedef Elem<DT> E;
     constexpr int EPC = E::EPC, ES = 16 / EPC;
     static_assert(EPC == 8, "16-bit storage types only");
     static_assert(WC == 64 || (WC == 32 && !TPOOL), "wave columns of 64 or 32 channels; the pooled tile order assumes 64");
-    constexpr int KS = KS1 + KS2, BM = 128, TN = WC / 16;
+    static_assert((BM == 128 || (BM == 64 && !TPOOL)) && NSLOT >= 2 && NSLOT <= 4, "tiles of 128 or 64 positions; the pooled row order assumes 128");
+    constexpr int KS = KS1 + KS2, TN = WC / 16, D = NSLOT - 1;
     constexpr int NWN = 256 / WC, NWM = 8 / NWN, WPOS = BM / NWM, MT = WPOS / 16;   // wave grid; positions, m-tiles per wave
     constexpr int SLAB = BM * 128, STAGE = KS * SLAB;  // bytes: one 64-channel K slab of the tile; one ring slot
     constexpr int PROW = WC + 4;                       // patch row stride in floats (pad: conflict-free b128 writes)
     constexpr int LPR = WC / 8, RPI = 64 / LPR, ITS = 16 / RPI;   // epilogue: lanes per row, rows per instruction, instructions per m-tile
+    constexpr int NR = MT * ITS;                       // residual loads = output stores of a wave per tile
+    constexpr int NPC = BM / 64;                       // DMA pieces of a wave per K slab
 
     extern __shared__ uint4 smem[];
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
@@ -57,7 +78,7 @@ __global__ __launch_bounds__(512, 1) void conv111_kernel(const C111Args a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int frow = lane & 15, fg = lane >> 4;
     const int wn = wave % NWN, wm = wave / NWN;        // channel group, position part
-    float* patch = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + 2 * STAGE) + wave * (16 * PROW);
+    float* patch = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + NSLOT * STAGE) + wave * (16 * PROW);
     // workgroup -> (channel column, tile stream).  Consecutive workgroup ids go round the 8 XCDs, each with its own
     // L2: the columns of one stream (they read the same activation tiles at the same time) are put on ONE XCD, so the
     // tile comes from HBM once and from that L2 ncol - 1 times (measured before: s3 `c` fetched its activations twice).
@@ -127,14 +148,14 @@ __global__ __launch_bounds__(512, 1) void conv111_kernel(const C111Args a) {
 #pragma unroll
         for (int s = 0; s < KS1; ++s)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < NPC; ++i)
                 blds16(row_live(xrow + 64 * i, live) ? xoff : kOutOfRange, d1, s * 128 + i * half_off, base + s * SLAB + i * (64 * 128));
         if (KS2) {
             const i32x4 d2 = make_desc(a.in2 + o * a.Cin2 * ES);
 #pragma unroll
             for (int s = 0; s < KS2; ++s)
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < NPC; ++i)
                     blds16(row_live(xrow + 64 * i, live) ? x2off : kOutOfRange, d2, s * 128 + i * half2_off, base + (KS1 + s) * SLAB + i * (64 * 128));
         }
     };
@@ -148,39 +169,57 @@ __global__ __launch_bounds__(512, 1) void conv111_kernel(const C111Args a) {
     auto k_row = [&](int k) { return (k / ITS) * 16 + (k % ITS) * RPI; };             // tile row of k relative to row0
     auto res_soff = [&](int k) { return (int)((row_off(k_row(k)) * a.Cout) * ES); };  // (row_off is additive over these bits)
     auto out_soff = [&](int k) { return (int)(((long long)(TPOOL ? row_pixel(k_row(k)) : k_row(k)) * a.out_ld) * ES); };
-    auto load_residual = [&](int tile, u32x4 (&r)[8]) {
+    auto load_residual = [&](int tile, u32x4 (&r)[NR]) {
         int live;
         const long long o = tile_origin(tile, live);
-        const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a.res + o * a.Cout * ES), (short)0, (int)kOutOfRange, 0x00020000);
+        const i32x4 rd = make_desc(a.res + o * a.Cout * ES);
 #pragma unroll
-        for (int k = 0; k < 8; ++k)
-            r[k] = __builtin_amdgcn_raw_buffer_load_b128(rd, row_live(row0 + k_row(k), live) ? res_lane : kOutOfRange, res_soff(k), 2);
+        for (int k = 0; k < NR; ++k)
+            r[k] = bload16_nt_uncounted(row_live(row0 + k_row(k), live) ? res_lane : kOutOfRange, rd, res_soff(k));
     };
 
     const int my_tiles = first < a.tiles ? (a.tiles - first + stride - 1) / stride : 0;
-    u32x4 rcur[8], rnext[8];
+    // tile q: activations in ring slot q % NSLOT, residual rows in register set q % NSLOT (the tile loop is unrolled NSLOT
+    // times: static slots and sets, nothing is copied)
+    u32x4 rs[NSLOT][NR];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) rnext[k] = u32x4{0u, 0u, 0u, 0u};
-    if (my_tiles > 0) {
-        issue_tile(first, 0);
-        if (RES) load_residual(first, rnext);
-    }
+    for (int u = 0; u < NSLOT; ++u)
+#pragma unroll
+        for (int k = 0; k < NR; ++k) rs[u][k] = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int j = 0; j < D; ++j)
+        if (j < my_tiles) {
+            issue_tile(first + j * stride, j);
+            if (RES) load_residual(first + j * stride, rs[j]);
+        }
     __builtin_amdgcn_sched_barrier(0);
+    // vector-memory operations of a wave per tile: loads (DMA pieces + residual rows) and stores.  Behind the loads of tile q
+    // the queue holds the loads of tiles q+1 .. q+D-1 and the stores of up to D earlier tiles, all issued by every wave in full
+    // (only the layer's last tile can be ragged, and its stores are nobody's predecessor): counted waits leave them in flight.
+    constexpr int NL = KS * NPC + (RES ? NR : 0), NS = TPOOL ? NR / 2 : NR;
+    static_assert((D - 1) * NL + D * NS <= 63, "vmcnt range");
 
-    for (int q = 0; q < my_tiles; ++q) {
-        const int tile = first + q * stride, slot = q & 1;
-        wait_vmcnt<0>();                                 // tile q's activations and residual rows have landed ...
-        __builtin_amdgcn_s_barrier();                    // ... for every wave, and nobody still reads slot (q+1)&1
+    for (int q0 = 0; q0 < my_tiles; q0 += NSLOT) {
+#pragma unroll
+    for (int u = 0; u < NSLOT; ++u) {
+        const int q = q0 + u;
+        if (q >= my_tiles) break;
+        const int tile = first + q * stride, slot = u;
+        u32x4 (&rcur)[NR] = rs[u];
+        // tile q's activations and residual rows have landed ...
+        if (D == 1) wait_vmcnt<0>();
+        else {
+            const int nl = my_tiles - 1 - q < D - 1 ? my_tiles - 1 - q : D - 1, ns = q < D ? q : D;
+            wait_counted<NL, NS, D>(nl, ns);
+        }
+        __builtin_amdgcn_s_barrier();                    // ... for every wave, and nobody still reads slot (q - 1) % NSLOT
         if (RES) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                rcur[k] = rnext[k];
-                asm volatile("" : "+v"(rcur[k]));        // the copy happens here, behind the wait above
-            }
+            for (int k = 0; k < NR; ++k) asm volatile("" : "+v"(rcur[k]));   // hipcc's own wait for the set sits here, behind ours
         }
-        if (q + 1 < my_tiles) {                          // one tile ahead: DMA the activations, load the residual rows
-            issue_tile(tile + stride, slot ^ 1);
-            if (RES) load_residual(tile + stride, rnext);
+        if (q + D < my_tiles) {                          // D tiles ahead: DMA the activations, load the residual rows
+            issue_tile(tile + D * stride, (u + D) % NSLOT);
+            if (RES) load_residual(tile + D * stride, rs[(u + D) % NSLOT]);
         }
         __builtin_amdgcn_sched_barrier(0);
 
@@ -262,16 +301,20 @@ __global__ __launch_bounds__(512, 1) void conv111_kernel(const C111Args a) {
             }
         }
     }
+    }
 }
 
-template <int DT, int KS1, int KS2, bool TPOOL, bool RES, int WC = 64>
+template <int DT, int KS1, int KS2, bool TPOOL, bool RES, int WC = 64, int BM = 128, int NSLOT = 2>
 static int launch111(const C111Args& a, int blocks, hipStream_t stream) {
-    const int lds = 2 * (KS1 + KS2) * 128 * 128 + 8 * 16 * (WC + 4) * 4;
-    AF_SET_MAX_LDS((&conv111_kernel<DT, KS1, KS2, TPOOL, RES, WC>), lds, "conv111");
-    hipLaunchKernelGGL((conv111_kernel<DT, KS1, KS2, TPOOL, RES, WC>), dim3(blocks), dim3(512), lds, stream, a);
+    const int lds = NSLOT * (KS1 + KS2) * BM * 128 + 8 * 16 * (WC + 4) * 4;
+    AF_SET_MAX_LDS((&conv111_kernel<DT, KS1, KS2, TPOOL, RES, WC, BM, NSLOT>), lds, "conv111");
+    hipLaunchKernelGGL((conv111_kernel<DT, KS1, KS2, TPOOL, RES, WC, BM, NSLOT>), dim3(blocks), dim3(512), lds, stream, a);
     AF_CHECK_LAUNCH("conv111_kernel");
     return AF_OK;
 }
+
+// positions per tile: 64 for K = 128 / 256 (16- / 32-KB stages, four of them in the ring), 128 for K = 64
+static int conv111_bm(const af_conv_desc* d) { return d->cin >= 128 ? 64 : 128; }
 
 // position tiles of the layer if it takes this path, 0 otherwise
 static long long conv111_tiles(const af_conv_desc* d, const af_conv_desc* d2, int out_ld) {
@@ -285,10 +328,11 @@ static long long conv111_tiles(const af_conv_desc* d, const af_conv_desc* d2, in
     if (d->tpool && (d->cin != 64 || d->t % 2 != 0)) return 0;
     const long long hw = (long long)d->h * d->w;
     if ((hw + 128) * 128 * 2 * 2 >= (1LL << 31)) return 0;                 // 32-bit row offsets inside a tile
-    const long long tiles = d->tpool ? (long long)d->n * (d->t / 2) * ((hw + 63) / 64) : ((long long)d->n * d->t * hw + 127) / 128;
+    const int bm = conv111_bm(d);
+    const long long tiles = d->tpool ? (long long)d->n * (d->t / 2) * ((hw + 63) / 64) : ((long long)d->n * d->t * hw + bm - 1) / bm;
     if (tiles >= (1LL << 30)) return 0;
     // persistent streams only pay with several tiles per workgroup (one clip of the deep stages stays on the generic path)
-    if (tiles * (d->cout / 256) < 4LL * device_cus()) return 0;
+    if (tiles * bm / 128 * (d->cout / 256) < 4LL * device_cus()) return 0;                // (counted in 128-position tiles)
     return tiles;
 }
 
@@ -317,9 +361,11 @@ int conv111_run(const af_conv_desc* d, const void* in, const void* w_packed, con
     if (d->tpool) return residual ? AF_C111(1, 0, true, true) : AF_C111(1, 0, true, false);
     if (d->cin == 64) return residual ? AF_C111(1, 0, false, true) : AF_C111(1, 0, false, false);
     if (d->cin == 256)     // 32-channel wave columns: the weights of 64 channels x 256 would not fit the registers
-        return residual ? (bf ? launch111<AF_BF16, 4, 0, false, true, 32>(a, blocks, stream) : launch111<AF_F16, 4, 0, false, true, 32>(a, blocks, stream))
-                        : (bf ? launch111<AF_BF16, 4, 0, false, false, 32>(a, blocks, stream) : launch111<AF_F16, 4, 0, false, false, 32>(a, blocks, stream));
-    return residual ? AF_C111(2, 0, false, true) : AF_C111(2, 0, false, false);
+        return residual ? (bf ? launch111<AF_BF16, 4, 0, false, true, 32, 64, 4>(a, blocks, stream) : launch111<AF_F16, 4, 0, false, true, 32, 64, 4>(a, blocks, stream))
+                        : (bf ? launch111<AF_BF16, 4, 0, false, false, 32, 64, 4>(a, blocks, stream) : launch111<AF_F16, 4, 0, false, false, 32, 64, 4>(a, blocks, stream));
+    // K = 128: tiles of 64 positions as well (16-KB stages), three tiles ahead
+    return residual ? (bf ? launch111<AF_BF16, 2, 0, false, true, 64, 64, 4>(a, blocks, stream) : launch111<AF_F16, 2, 0, false, true, 64, 64, 4>(a, blocks, stream))
+                    : (bf ? launch111<AF_BF16, 2, 0, false, false, 64, 64, 4>(a, blocks, stream) : launch111<AF_F16, 2, 0, false, false, 64, 64, 4>(a, blocks, stream));
 #undef AF_C111
 }
 
