@@ -38,6 +38,12 @@ __device__ __forceinline__ u32x4 bload16_nt_uncounted(unsigned voff, const i32x4
     asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen nt" : "=v"(r) : "v"(voff), "s"(desc), "s"(soff) : "memory");
     return r;
 }
+// (the same for a 64-bit address)
+__device__ __forceinline__ uint4 gload16_uncounted(const void* p) {
+    u32x4 r;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r) : "v"(p) : "memory");
+    return __builtin_bit_cast(uint4, r);
+}
 // raw buffer descriptor over [base, base + 2 GiB): stride 0, no swizzle, 32-bit data format
 __device__ __forceinline__ i32x4 make_desc(const char* base) {
     const unsigned long long b = (unsigned long long)base;

@@ -123,7 +123,7 @@ __global__ __launch_bounds__(512, 2) void conv_ca_kernel(const CAArgs a) {
         for (int i = 0; i < TN; ++i)
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
-                dst[i][kk] = *reinterpret_cast<const uint4*>(wsrc + ((long long)(kc * 64 + i * 16 + frow) * 64 + kk * 32 + fg * 8) * 2);
+                dst[i][kk] = gload16_uncounted(wsrc + ((long long)(kc * 64 + i * 16 + frow) * 64 + kk * 32 + fg * 8) * 2);
     };
     auto load_b = [&](uint4 (&dst)[TM][2], const char* bsrc, int tile) {
         const int n = tile / a.chunks, hw0 = (tile % a.chunks) * P;
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(512, 2) void conv_ca_kernel(const CAArgs a) {
             const int pc = hw0 + p < a.HW ? p : 0;                    // a pixel beyond the frame: any valid row (its outputs are dropped)
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
-                dst[j][kk] = *reinterpret_cast<const uint4*>(bb + (((long long)t * a.HW + pc) * 64 + kk * 32 + fg * 8) * 2);
+                dst[j][kk] = gload16_uncounted(bb + (((long long)t * a.HW + pc) * 64 + kk * 32 + fg * 8) * 2);
         }
     };
 
@@ -167,22 +167,37 @@ __global__ __launch_bounds__(512, 2) void conv_ca_kernel(const CAArgs a) {
     for (int q = 0; q < total; ++q) {
         // weights(q) and image(q) have landed once only image(q+1)'s pieces (issued right behind weights(q)) and the 4 trunk-row
         // stores of the previous iteration are still in flight (the 8 `a` output stores behind a tile's last slab are waited for:
-        // once per tile, and the count does not depend on how hipcc emits them)
+        // once per tile, and the count does not depend on how hipcc emits them; leaving them in flight too measured no gain)
         if (q == 0) wait_vmcnt<0>();
         else if (!DUAL && q + 1 < total) { if (five) wait_vmcnt<9>(); else wait_vmcnt<8>(); }
         else wait_vmcnt<4>();
         __builtin_amdgcn_s_barrier();                                // ... for everyone; weight slot (q+1)&1, image slot (q+2)%3 are free
+        // (the c weights / b fragments are loads hipcc does not count - its own waits for them were vmcnt(7)..(0) at this point,
+        //  which drained the image DMA issued behind them: ONE stage in flight instead of two; the empty asm orders the copies
+        //  behind our wait)
         if (!DUAL) {
 #pragma unroll
-            for (int i = 0; i < TN; ++i) { wcur[i][0] = wnext[i][0]; wcur[i][1] = wnext[i][1]; }
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    u32x4 t = __builtin_bit_cast(u32x4, wnext[i][kk]);
+                    asm volatile("" : "+v"(t));
+                    wcur[i][kk] = __builtin_bit_cast(uint4, t);
+                }
         }
         if (c_kc == 0) {
 #pragma unroll
             for (int j = 0; j < TM; ++j)
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
-                    bcur[j][kk] = bnext[j][kk];
-                    if (DUAL) x0cur[j][kk] = x0next[j][kk];
+                    u32x4 t = __builtin_bit_cast(u32x4, bnext[j][kk]);
+                    asm volatile("" : "+v"(t));
+                    bcur[j][kk] = __builtin_bit_cast(uint4, t);
+                    if (DUAL) {
+                        u32x4 t0 = __builtin_bit_cast(u32x4, x0next[j][kk]);
+                        asm volatile("" : "+v"(t0));
+                        x0cur[j][kk] = __builtin_bit_cast(uint4, t0);
+                    }
                 }
         }
         const bool last = c_kc + 1 == a.kslabs;
