@@ -220,6 +220,10 @@ CONV_CASES = [
     ("stream111_128to512_res_ragged", 128, 512, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 6, 107, 109), False, True),
     ("stream111_256to1024_res_ragged", 256, 1024, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 4, 91, 93), True, True),   # 32-channel wave columns
     ("stream111_64to768_three_columns", 64, 768, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 5, 95, 97), True, True),    # grid not a multiple of 8 x columns
+    # K = 128 / 256 run 64-position tiles through a 4-slot ring (three tiles ahead, counted waits): without a residual the
+    # per-tile operation counts differ; ragged last tiles
+    ("stream111_128to256_nores_ragged", 128, 256, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 13, 101, 103), True, False),
+    ("stream111_256to512_nores_ragged", 256, 512, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 7, 99, 101), False, False),
     # frame / band resident 1x3x3 (the s3 / s4 `b` convs at bench size: >= 192 work units): whole 14x14 frames, 256 channels,
     # 1 and 3 K slabs (the third slab's patch is issued inside the loop); a 13-row frame; s3's 28x28 in two bands of 14
     # rows; 27x26 (bands of 14 + 13 rows, narrower pitch); no ReLU
@@ -235,6 +239,7 @@ EXPECT_VARIANT = {"tile256_1x3x3_res": 6, "tile256_ragged_m": 6, "tile512_1x3x3_
                   "stream111_128to512_res_ragged": {"f32": 5, "f16": 10, "bf16": 10},
                   "stream111_256to1024_res_ragged": {"f32": 5, "f16": 10, "bf16": 10},
                   "stream111_64to768_three_columns": {"f32": 2, "f16": 10, "bf16": 10},
+                  "stream111_128to256_nores_ragged": {"f16": 10, "bf16": 10}, "stream111_256to512_nores_ragged": {"f16": 10, "bf16": 10},
                   "halo133_64to256_14x14": {"f32": 6, "f16": 11, "bf16": 11}, "halo133_192to256_13x14": {"f32": 6, "f16": 11, "bf16": 11},
                   "halo133_128to128_28x28": {"f32": 7, "f16": 11, "bf16": 11},
                   "halo133_256to128_27x26_norelu": {"f32": 7, "f16": 11, "bf16": 11}}
@@ -264,8 +269,8 @@ def test_conv_vs_oracle(case, dtype):
     got = hh.conv_bn_act(hh.to_ndhwc(x, dtype), sd["w.weight"], *hh.fold_bn(sd, "bn"), s, p, relu, dtype,
                          residual=None if res is None else hh.to_ndhwc(res, dtype))
     if name in EXPECT_VARIANT:
-        want_variant = EXPECT_VARIANT[name][dtype] if isinstance(EXPECT_VARIANT[name], dict) else EXPECT_VARIANT[name]
-        assert hh.conv_bn_act.last_variant == want_variant, hh.conv_bn_act.last_variant
+        want_variant = EXPECT_VARIANT[name].get(dtype) if isinstance(EXPECT_VARIANT[name], dict) else EXPECT_VARIANT[name]
+        assert want_variant is None or hh.conv_bn_act.last_variant == want_variant, hh.conv_bn_act.last_variant
     tol = {"f32": 2e-6, "f16": 1.5e-3, "bf16": 1.2e-2}[dtype]     # operands pre-rounded: only output rounding + fp32 accumulation remain
     got = hh.to_ncdhw(got).double()
     err = (got - want).abs().max().item()
