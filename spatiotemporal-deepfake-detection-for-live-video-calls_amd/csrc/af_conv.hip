@@ -561,7 +561,9 @@ static int pick_variant(int cout, int cin, int taps, int dtype, long long M, int
     // a handful of rows (the FTCN-TT head: 17 tokens per clip): the smallest tile, so that at least the channel
     // dimension spreads over the CUs
     if ((M + 255) / 256 * (cout / (wide ? 128 : 64)) < 64) return VAR_64x128;
-    if (wide && !short_k && ksteps <= 8 && cout >= 512) return VAR_128x128_R2;   // wide-output streams, 4..8 K-steps
+    // wide-output streams of 4..8 K-steps, and the 512 -> 128 `a` convs of s3 (8 K-steps; measured 60 -> 50 us against the
+    // 128x256 tile): two workgroups per CU cover each other's load / store phases
+    if (wide && !short_k && ksteps <= 8 && (cout >= 512 || cout == 128)) return VAR_128x128_R2;
     return wide ? (short_k ? VAR_128x128 : VAR_128x256) : (short_k ? VAR_64x128 : VAR_64x256);
 }
 
