@@ -1,4 +1,6 @@
-"""Run ON THE GPU BOX: ablation timing of one conv111 layer (temporary AF_C111_ABL switches)."""
+"""Run ON THE GPU BOX: device time of single conv layers through the C ABI (the s4 / s3 / s2 `c` convs by default); `layer` and
+`timeit` are also used by exp_tile_overhead.py / exp_variants.py.  (The ablation numbers in DESIGN 3.1d came from temporary
+kernel switches that are not in the tree.)"""
 import os, sys, ctypes as C
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
