@@ -370,7 +370,7 @@ def test_two_stream_mode_matches_single_stream(weights0):
     assert y17.shape == (17,) and (y17[:16] - want).abs().max().item() <= LOGIT_TOL["f16"] and abs(float(y17[16] - want[0])) <= LOGIT_TOL["f16"]
 
 
-@pytest.mark.parametrize("batch", [3, 5, 12, 13])
+@pytest.mark.parametrize("batch", [3, 5, 7, 12, 13, 24])
 def test_kernel_selection_thresholds_across_batch_sizes(weights0, batch):
     """The engine picks kernels by batch (conv_ca from 3 clips, conv133g for s3 from 6 and for s4 from 12, split-K below, the
     persistent streams from 4 tiles per CU ...): the f16 engine at batch sizes around those thresholds against the exact-fp32
