@@ -312,9 +312,14 @@ __global__ __launch_bounds__(512, 2) void conv_ca_kernel(const CAArgs a) {
     }
 }
 
+// dynamic LDS of a launch: a-weight ring (2 slots) + image slot(s) (+ both c-side weight sets, DUAL) + the BN parameters
+static long long conv_ca_lds_bytes(bool dual, int P, int C) {
+    return 2LL * 3 * 64 * 128 + (dual ? (256LL + 2 * P) * 128 + 2LL * C * 128 : 3LL * (256 + 2 * P) * 128) + (2LL * C + 128) * 4;
+}
+
 template <int DT, bool DUAL>
 static int launch_ca(const CAArgs& a, int blocks, hipStream_t stream) {
-    const int lds = 2 * 3 * 64 * 128 + (DUAL ? (256 + 2 * a.P) * 128 + 2 * a.C * 128 : 3 * (256 + 2 * a.P) * 128) + (2 * a.C + 128) * 4;
+    const int lds = (int)conv_ca_lds_bytes(DUAL, a.P, a.C);
     if (lds > 160 * 1024) return set_error(AF_ERR_ARG, "conv_ca: %d bytes of LDS needed", lds);
     AF_SET_MAX_LDS((&conv_ca_kernel<DT, DUAL>), 160 * 1024, "conv_ca");
     hipLaunchKernelGGL((conv_ca_kernel<DT, DUAL>), dim3(blocks), dim3(512), lds, stream, a);
@@ -339,6 +344,9 @@ bool conv_ca_applies(const af_conv_desc* dc, const af_conv_desc* d1, const af_co
     const long long hw = (long long)dc->h * dc->w;
     if ((long long)dc->t * hw * dc->cout * 2 >= (1LL << 31)) return false;     // 32-bit offsets inside a clip
     const int p = 256 / dc->t;
+    // the launch must fit LDS (wide trunks: the plain form with T = 16 and C >= 512, the projection form with C >= 512 do not):
+    // such a pair keeps its two launches instead of failing in launch_ca
+    if (conv_ca_lds_bytes(d1 != nullptr, p, dc->cout) > 160 * 1024) return false;
     // whole tiles only: the kernel's counted s_waitcnt vmcnt assume that every wave issues every store of an iteration; a
     // ragged last chunk could mask ALL lanes of a wave's store, hipcc would branch around it and the count would be off
     if (hw % p != 0) return false;

@@ -287,7 +287,8 @@ __global__ __launch_bounds__(256) void dual_head_kernel(const float* z, const fl
 }
 
 // AltFreezingRGBEncoder.forward with from_features (dualrun/model/dual_rgb.py:27-44) + rgb_proj (:70, no bias):
-//   zv[b] = sum_t V[b][t] * w[b][t],  w = valid / max(sum valid, 1e-6)  (no mask: the plain mean over tv frames),
+//   zv[b] = sum_t V[b][t] * w[b][t],  w = valid / sum_t max(valid[t], 1e-6)  - the reference clamps EACH element before the
+//   sum (:42-43), so the denominator is nvalid + (T - nvalid) * 1e-6  (no mask: the plain mean over tv frames),
 //   z[b][0..d) = zv[b] @ Wt   (Wt = rgb_proj.weight^T, [vis][d])
 // `lengths` counts the valid frames of a mask over `tmask` frames; V has tv == tmask frames, or tv == 1 (broadcast over
 // the mask as torch does: the weights then sum to 1, or to 0 for a clip with no valid frame).  One workgroup per clip.
@@ -297,7 +298,7 @@ __global__ __launch_bounds__(256) void masked_mean_proj_kernel(const float* v, i
     const int tid = threadIdx.x, clip = blockIdx.x;
     int nvalid = lengths ? lengths[clip] : tmask;
     nvalid = nvalid < 0 ? 0 : (nvalid > tmask ? tmask : nvalid);
-    const float inv = lengths ? 1.f / fmaxf((float)nvalid, 1e-6f) : 1.f / (float)tv;
+    const float inv = lengths ? 1.f / ((float)nvalid + (float)(tmask - nvalid) * 1e-6f) : 1.f / (float)tv;
     for (int k = tid; k < vis; k += 256) {
         float s = 0.f;
         if (tv == 1) s = lengths ? v[(long long)clip * vis + k] * ((float)nvalid * inv) : v[(long long)clip * vis + k];

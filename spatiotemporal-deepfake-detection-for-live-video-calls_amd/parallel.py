@@ -15,17 +15,24 @@ def env_rank_world() -> Tuple[int, int, int]:
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
-def init(backend: str = None) -> Tuple[int, int, int]:
-    """Initialises torch.distributed from the torchrun environment (no-op for a single process)."""
+def init(backend: str = None, timeout_s: float = 120.0) -> Tuple[int, int, int]:
+    """Initialises torch.distributed from the torchrun environment (no-op for a single process).
+    With the RCCL backend the process group is bound to this rank's GPU (``device_id``), so the communicator is created
+    eagerly on the right device and barriers need no device guess; ``timeout_s`` bounds the rendezvous and every
+    collective (a rank that died before joining makes the others fail within that time instead of hanging)."""
+    import datetime
     rank, local_rank, world = env_rank_world()
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
+        kw = {}
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            kw["device_id"] = torch.device("cuda", local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world,
+                                timeout=datetime.timedelta(seconds=timeout_s), **kw)
     return rank, local_rank, world
 
 

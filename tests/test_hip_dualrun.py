@@ -176,3 +176,55 @@ def test_two_stream_model_as_one_unit(dual_rgb):
     msd = {k: v.detach().cpu() for k, v in moe.state_dict().items()}
     wz, wg = dualrun_oracle.gated_moe(msd, want_logit, want_dual.view(B, 1))
     np.testing.assert_allclose(z.cpu().numpy(), wz.numpy(), rtol=0, atol=2e-4)
+
+
+@pytest.fixture(scope="module")
+def config3_oracle(dual_rgb):
+    """BASELINE config[3] at its own size: bench.py's rank-0 batch (16 uniform uint8 clips, seed 2026, W(0)); the CPU oracles
+    (AltFreezing fp32 forward -> pooled feature -> DualEncoderRGB -> GatedMoE) on the first 4 clips."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import i3d_oracle
+    g, sp, sd, net = dual_rgb
+    B, n = 16, 4
+    sdc = synth.synthetic_state_dict(seed=0)
+    u8 = synth.synthetic_clips_u8(B, seed=2026, kind="uniform")
+    A, L, lengths = dualrun.synthetic_dual_inputs(B, sp, frames=8, seed=2026)
+    want_logit, stages = i3d_oracle.forward(sdc, synth.normalize_like_callers(u8[:n]), return_stages=True)
+    feat = stages["avgpool"].reshape(n, 1, -1)
+    want_dual, _ = dualrun_oracle.dual_rgb_forward(sd, A[:n], L[:n], feat, dualrun_oracle.lengths_to_mask(lengths[:n], 8), heads=4, tau=0.7)
+    return sdc, u8, A, L, lengths, want_logit, feat.view(n, -1), want_dual
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+def test_config3_full_size_two_stream(dual_rgb, config3_oracle, dtype):
+    """The composite bench.py --model dualrun_rgb times, as one model at its own size: 16 uint8 clips of 32x224x224 ->
+    forward_clips_u8(return_pooled=True) on the 16-bit trunk -> DualEncoderRGB (V = the pooled feature) -> GatedMoE with the
+    AltFreezing logit (reference dualrun/model/dual_rgb.py:47-122, rgb/engine_rgb.py:369-404); every stage against its oracle
+    on 4 of the clips: AltFreezing logit <= 1e-3 (f16) / the bf16 bound, pooled feature, dual logit, fused logit."""
+    from af_mi355x.classifier import Classifier
+    g, sp, sd, net = dual_rgb
+    sdc, u8, A, L, lengths, want_logit, want_feat, want_dual = config3_oracle
+    B, n = 16, 4
+    clf = Classifier(precision=dtype)
+    clf.network.load_state_dict(sdc)
+    clf = clf.cuda().eval()
+    mask = net.lengths_to_mask(lengths, 8, "cuda")
+    moe = dualrun.GatedMoE().cuda().eval()
+    with torch.inference_mode():
+        rgb = clf.network.forward_clips_u8(u8.cuda(), return_pooled=True)
+        z_dual = net(A.cuda(), L.cuda(), rgb["pooled"].view(B, 1, -1), key_padding_mask=mask)
+        z, gate = moe(rgb["final_output"], z_dual.view(B, 1))
+    assert (dtype, B, (32, 224, 224)) in clf.network._engines                      # the B=16 plan, not a shrunken one
+    logit_tol = {"f16": 1e-3, "bf16": 1e-2}[dtype]                                 # north-star tolerance / tests' BF16_TOL
+    feat_tol = {"f16": 2e-3, "bf16": 2e-2}[dtype]                                  # pooled features are O(1): relative to their scale
+    e_logit = (rgb["final_output"][:n].cpu() - want_logit).abs().max().item()
+    e_feat = (rgb["pooled"][:n].cpu() - want_feat).abs().max().item() / want_feat.abs().max().item()
+    e_dual = (z_dual[:n].cpu() - want_dual).abs().max().item()
+    msd = {k: v.detach().cpu() for k, v in moe.state_dict().items()}
+    wz, _ = dualrun_oracle.gated_moe(msd, want_logit, want_dual.view(n, 1))
+    e_fused = (z[:n].cpu() - wz).abs().max().item()
+    print("config[3] %s: logit %.2e pooled(rel) %.2e dual %.2e fused %.2e" % (dtype, e_logit, e_feat, e_dual, e_fused))
+    assert torch.isfinite(z).all() and z.shape == (B, 1)
+    assert e_logit <= logit_tol and e_feat <= feat_tol, (e_logit, e_feat)
+    # the dual logit sees the trunk's rounding only through rgb_proj of the pooled feature; the fused logit mixes both
+    assert e_dual <= logit_tol and e_fused <= logit_tol, (e_dual, e_fused)

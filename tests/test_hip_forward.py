@@ -391,3 +391,77 @@ def test_kernel_selection_thresholds_across_batch_sizes(weights0, batch):
     err = (out["f16"] - out["f32"]).abs().max().item()
     print("B=%d f16 vs f32 engine: max|d| %.3e" % (batch, err))
     assert err <= LOGIT_TOL["f16"], (batch, err)
+
+
+def test_f16_overflow_gives_non_finite_logit_like_fp16_autocast():
+    """The f16 engine stores activations as fp16 like the reference under torch.amp.autocast (test/af_realtime.py:70,84): a
+    conv output beyond 65 504 becomes inf there and the clip's logit ends up inf / NaN.  The engine must do the same - never
+    a plausible number from a silently saturated activation - and must leave the other clips of the batch alone.  Set-up:
+    the shrunken network with s3.res0's a_bn gain x8 and clip 1's pixels x1e4 (still fp16-representable): in fp32 the
+    clip's s3.res0 `a` output passes 65 504 (asserted on the oracle), clips 0 and 2 stay O(1)."""
+    clip_size, size = 8, 64
+    from af_mi355x.arch import i3d_r50_spec
+    sd = synth.synthetic_state_dict(i3d_r50_spec(clip_size, size), seed=5)
+    sd = {k: v.clone() for k, v in sd.items()}
+    sd["resnet.s3.pathway0_res0.branch2.a_bn.weight"] *= 8.0
+    u8 = synth.synthetic_clips_u8(3, seed=9, kind="smooth", num_frames=clip_size, size=size)
+    x = synth.normalize_like_callers(u8)
+    x[1] *= 1e4
+    assert x.abs().max().item() < 65504.0                                  # the input itself is representable
+    want, stages = oracle.forward(sd, x, num_frames=clip_size, crop=size, return_stages=True)
+    a_out = oracle.conv_bn_act(stages["pool"], sd["resnet.s3.pathway0_res0.branch2.a.weight"], sd,
+                               "resnet.s3.pathway0_res0.branch2.a_bn", (1, 1, 1), (1, 0, 0), relu=True)
+    assert a_out[1].max().item() > 65504.0 and a_out[[0, 2]].max().item() < 1e3 and stages["s2"].abs().max().item() < 65504.0
+    # the expectation under fp16 STORAGE of every conv output (what autocast's fp16 conv results are), stated by the oracle
+    orig = oracle.conv_bn_act
+    try:
+        oracle.conv_bn_act = lambda *a, **k: orig(*a, **k).half().float()
+        want16 = oracle.forward(sd, x, num_frames=clip_size, crop=size)
+    finally:
+        oracle.conv_bn_act = orig
+    assert not torch.isfinite(want16[1]).any() and torch.isfinite(want16[[0, 2]]).all() and torch.isfinite(want).all()
+    clf = Classifier(clip_size=clip_size, precision="f16", crop_size=size)
+    clf.network.load_state_dict(sd)
+    clf = clf.to("cuda").eval()
+    with torch.inference_mode():
+        got = clf(x.cuda())["final_output"].cpu()
+        s = clf.network.forward(x.cuda(), return_scores=True)["scores"].cpu()
+    print("f16 overflow: engine", got.flatten().tolist(), "fp16-storage oracle", want16.flatten().tolist(), "fp32 oracle", want.flatten().tolist())
+    assert not torch.isfinite(got[1]).any(), got
+    assert (got[[0, 2]] - want[[0, 2]]).abs().max().item() <= 1e-3, (got, want)
+    assert not (s[1] > 0.0 and s[1] < 1.0) or not torch.isfinite(got[1]).any()    # the score is not a plausible probability either
+    # the fp32 engine represents the same activations and stays finite, equal to the fp32 oracle (relative: |logit| is O(1e3))
+    clf32 = Classifier(clip_size=clip_size, precision="f32", crop_size=size)
+    clf32.network.load_state_dict(sd)
+    clf32 = clf32.to("cuda").eval()
+    with torch.inference_mode():
+        g32 = clf32(x.cuda())["final_output"].cpu()
+    assert torch.isfinite(g32).all() and ((g32 - want).abs() / want.abs().clamp_min(1.0)).max().item() <= 1e-4
+
+
+def test_bench_two_rank_rehearsal_shards_the_real_forward():
+    """SURVEY 8e on the REAL forward: `AF_BENCH_REHEARSAL=1 bench.py --gpus 2` starts two rank processes (gloo, both on this
+    one GPU: RCCL needs a GPU per rank), each runs its own shard of clips through the HIP forward, the logits are all-gathered
+    in clip order; the line must say n_gpus == 2 and the gathered logits must equal a single-process forward of the same
+    clips.  (Two child processes + this one on the GPU; run once.)"""
+    import json
+    import subprocess
+    B = 2
+    env = dict(os.environ, AF_BENCH_REHEARSAL="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", str(B),
+                        "--cpu-clips", "0", "--no-roofline", "--emit-logits"], env=env, capture_output=True, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    line = json.loads(p.stdout.decode().strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["config"]["global_batch"] == 2 * B
+    assert "roofline" not in line and "N=1" in line["note"]
+    sd = synth.synthetic_state_dict(seed=0)
+    clf = Classifier(precision="bf16")
+    clf.network.load_state_dict(sd)
+    clf = clf.cuda().eval()
+    u8 = torch.cat([synth.synthetic_clips_u8(B, seed=2026 + r, kind="uniform") for r in range(2)])     # rank r's batch, in rank order
+    with torch.inference_mode():
+        ya = clf(synth.normalize_like_callers(u8[:B].cuda()))["final_output"].float().cpu().flatten()
+        yb = clf(synth.normalize_like_callers(u8[B:].cuda()))["final_output"].float().cpu().flatten()
+    want = torch.cat([ya, yb])
+    got = torch.tensor(line["gathered_logits"])
+    assert got.shape == want.shape and torch.equal(got, want), (got, want)

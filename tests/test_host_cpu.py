@@ -249,3 +249,122 @@ def test_rgb3_stem_sizes():
     assert L.af_stem_input_bytes_rgb3(1, 32, 224, 224, 1) == (36 * 230 + 8) * row
     assert L.af_packed_stem_weight_bytes_rgb3(5, 1) == 27 * 4 * 64 * 16 and L.af_packed_stem_weight_bytes_rgb3(1, 2) == 6 * 4 * 64 * 16
     assert L.af_stem_input_bytes_rgb3(1, 32, 224, 224, 0) < 0                                  # fp32 keeps the 4-channel layout
+
+
+def test_conv_ca_is_not_offered_where_its_lds_does_not_fit():
+    """af_conv_ca_fusable must agree with what launch_ca can run: the fused c -> a pair needs 2 a-weight slots + 3 image
+    slots (plain) or 1 image slot + both c-side weight sets (projection); with a 512-wide trunk that is > 160 KB and the
+    engine has to keep the two launches (it used to plan the fused op and fail every forward with AF_ERR_ARG)."""
+    import ctypes as C
+    from af_mi355x import _lib
+    L = _lib.lib
+    c = lambda cout, t=32: _desc(64, t, 56, 56, 64, cout, (1, 1, 1), (1, 1, 1), (0, 0, 0))
+    a = lambda cin, t=32: _desc(64, t, 56, 56, cin, 64, (3, 1, 1), (1, 1, 1), (1, 0, 0))
+    b1 = lambda cout, t=32: _desc(64, t, 56, 56, 64, cout, (1, 1, 1), (1, 1, 1), (0, 0, 0), relu=0)
+    assert L.af_conv_ca_fusable(C.byref(c(256)), None, C.byref(a(256))) == 1                      # s2 as shipped
+    assert L.af_conv_ca_fusable(C.byref(c(256)), C.byref(b1(256)), C.byref(a(256))) == 1
+    assert L.af_conv_ca_fusable(C.byref(c(512, 16)), None, C.byref(a(512, 16))) == 0              # 164 352 B > 163 840 B
+    assert L.af_conv_ca_fusable(C.byref(c(512)), C.byref(b1(512)), C.byref(a(512))) == 0          # > 217 KB
+    assert L.af_conv_ca_fusable(C.byref(c(1024, 16)), None, C.byref(a(1024, 16))) == 0
+    assert L.af_conv_ca_fusable(C.byref(c(1024)), None, C.byref(a(1024))) == 1                    # T = 32 (8-pixel tiles): 162 304 B fits
+
+
+def test_self_launch_returns_quickly_when_a_rank_dies():
+    """bench.self_launch polls ALL children: rank 1 dies at start-up (AF_BENCH_FAIL_RANK), rank 0 would wait in the
+    rendezvous for the process-group timeout - the parent must terminate it, relay the failure and return 1 in seconds."""
+    import subprocess
+    import sys
+    import time
+    env = dict(os.environ, AF_BENCH_FAIL_RANK="1", AF_BENCH_REHEARSAL="1")
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--cpu-clips", "0",
+                        "--no-roofline"], env=env, capture_output=True, timeout=120)
+    dt = time.time() - t0
+    assert p.returncode == 1, (p.returncode, p.stderr.decode()[-2000:])
+    assert b"rank 1 exited with code 3" in p.stderr and p.stdout.strip() == b""
+    assert dt < 30.0, dt                                            # (python + torch start-up of the children included)
+
+
+def _device_asm(src):
+    """gfx950 assembly of one .hip source (device side only; no GPU needed)"""
+    import subprocess
+    out = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "--offload-device-only", "-S", "-o", "-", src],
+                         capture_output=True, timeout=600)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    return out.stdout.decode()
+
+
+def _regs_of(text):
+    regs = set()
+    for m in re.finditer(r"\bv\[(\d+):(\d+)\]|\bv(\d+)\b", text):
+        if m.group(3) is not None:
+            regs.add(int(m.group(3)))
+        else:
+            regs.update(range(int(m.group(1)), int(m.group(2)) + 1))
+    return regs
+
+
+def test_hand_counted_vmcnt_kernels_have_no_spills_and_no_early_use_of_uncounted_loads():
+    """Build-time guard for the kernels whose vector-memory waits are hand counted (LDS-DMA + inline-asm loads that hipcc
+    does not see): (1) no kernel of the library spills or uses scratch - a scratch reload's vmcnt(0), or a
+    spilled destination of an in-flight load, would break the counts silently; (2) between every inline-asm register load
+    (`bload16_nt_uncounted` / `gload16_uncounted`: a buffer / global load inside an ASMSTART block, without `lds`) and the
+    next `s_waitcnt vmcnt` in straight-line code, no instruction reads or writes its destination registers (a phi copy or
+    v_mov of a pending register would read stale data)."""
+    from concurrent.futures import ThreadPoolExecutor
+    csrc = os.path.join(ROOT, "spatiotemporal-deepfake-detection-for-live-video-calls_amd", "csrc")
+    files = sorted(f for f in os.listdir(csrc) if f.endswith(".hip"))
+    with ThreadPoolExecutor(max_workers=6) as ex:
+        asms = dict(zip(files, ex.map(lambda f: _device_asm(os.path.join(csrc, f)), files)))
+    n_kernels = n_loads = 0
+    for f, asm in asms.items():
+        names = re.findall(r"^\s*\.name:\s+(\S+)$", asm, re.M)
+        spills = [int(v) for v in re.findall(r"\.vgpr_spill_count:\s+(\d+)", asm)]
+        scratch = [int(v) for v in re.findall(r"^\s*\.private_segment_fixed_size:\s+(\d+)", asm, re.M)]
+        kernels = [n for n in names if n.startswith("_Z")]
+        n_kernels += len(spills)
+        if not spills:
+            continue                                            # a file without kernels (af_api.hip: the op-list runner)
+        assert len(spills) == len(scratch), f
+        # a spilling kernel is tolerated only if every vector-memory wait in it is a full drain (vmcnt(0)): then a scratch
+        # reload cannot be miscounted (conv133g's b + c fused instantiation - off by default - is such a kernel)
+        counted = set()
+        for seg in re.split(r"^\.Lfunc_end\d+:", asm, flags=re.M):
+            lab = re.findall(r"^(_Z\w+):", seg, re.M)
+            if lab and re.search(r"s_waitcnt vmcnt\(([1-9]\d*)\)", "\n".join(
+                    b for b in re.findall(r";;#ASMSTART(.*?);;#ASMEND", seg, re.S))):
+                counted.add(lab[-1])
+        bad = [(k, s, p) for k, s, p in zip(kernels, spills, scratch) if (s or p) and k in counted]
+        assert not bad, "%s: kernels with hand-counted vmcnt waits AND VGPR spills / scratch: %s" % (f, bad)
+        n_counted = locals().get("n_counted", 0) + len(counted)
+        lines = asm.splitlines()
+        in_asm = False
+        for i, ln in enumerate(lines):
+            t = ln.strip()
+            if t.startswith(";;#ASMSTART"):
+                in_asm = True
+                continue
+            if t.startswith(";;#ASMEND"):
+                in_asm = False
+                continue
+            if not in_asm or " lds" in t or not re.match(r"(buffer|global)_load_dword", t):
+                continue
+            n_loads += 1
+            dest = _regs_of(t.split(",")[0])
+            assert dest, t
+            for j in range(i + 1, len(lines)):
+                u = lines[j].strip()
+                if not u or u.startswith(";") or u.startswith("."):
+                    if re.match(r"\.LBB\d+_\d+:", u):
+                        break                                   # a label: control flow merges, the linear scan ends
+                    continue
+                if u.startswith("s_waitcnt") and "vmcnt" in u:
+                    break
+                if u.startswith(("s_cbranch", "s_branch", "s_endpgm", "s_setpc")):
+                    break
+                # the address operand of ANOTHER load may reuse no destination register either; any mention counts
+                hit = dest & _regs_of(u)
+                assert not hit, "%s: v%s is the destination of a pending uncounted load (line %d: %s) but is touched by line %d: %s" % (
+                    f, sorted(hit), i + 1, t, j + 1, u)
+    assert n_counted >= 10, n_counted                              # ... including the kernels with counted waits
+    assert n_kernels >= 40 and n_loads >= 8, (n_kernels, n_loads)   # the lint saw the kernels / loads it is meant for
