@@ -551,7 +551,7 @@ def bench_aligner(args, rank, world, dev):
 def bench_conv3x3x3(args, rank, world, dev):
     """The literal "MFMA % on 3x3x3 Conv3d" of BASELINE.json's metric.  SYNTHETIC - NOT A LAYER OF THE REFERENCE MODEL (its
     bottleneck is factorised into 3x1x1 + 1x3x3): the generic kT x kH x kW implicit-GEMM kernel with a full
-    3x3x3 kernel on the geometry of SURVEY 8d shape #4 (64 -> 64 @ 32x56x56, K = 1728) and #18 (256 -> 256 @ 16x14x14,
+    3x3x3 kernel (round 3: the frame-resident halo kernel conv133g with kT = 3) on the geometry of SURVEY 8d shape #4 (64 -> 64 @ 32x56x56, K = 1728) and #18 (256 -> 256 @ 16x14x14,
     K = 6912), batch 16, Conv3d + BN + ReLU in one launch; parity against F.conv3d (fp32, CPU) on clip 0."""
     import ctypes as C
     import torch.nn.functional as F
@@ -614,8 +614,8 @@ def bench_conv3x3x3(args, rank, world, dev):
             % (args.dtype, PEAK_TFLOPS[args.dtype]), "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(tot_ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
             "data": "synthetic",
-            "config": {"workload": "Conv3d 3x3x3 (stride 1, pad 1) + BN + ReLU, batch=%d, generic implicit-GEMM kernel "
-                                   "(af_conv3d_bn_act), SURVEY 8d shapes #4 and #18 with kT=3" % B},
+            "config": {"workload": "Conv3d 3x3x3 (stride 1, pad 1) + BN + ReLU, batch=%d, af_conv3d_bn_act (kernel per shape in "
+                                   "`shapes`), SURVEY 8d shapes #4 and #18 with kT=3" % B},
             "shapes": shapes}
     if rank == 0:
         print(json.dumps(line), flush=True)

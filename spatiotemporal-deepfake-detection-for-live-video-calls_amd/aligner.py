@@ -5,9 +5,12 @@
 One similarity transform is fitted over the 5-point landmarks of ALL frames of a clip (test_tools/warp_for_xray.py:556-560:
 least squares for a non-reflective similarity and for its mirror image, the smaller residual wins), the 68-point landmarks
 are mapped through it, and every frame's crop is pasted on a common canvas and warped to ``size`` x ``size``.  The fit is
-a 4-unknown least-squares problem on T*5 points and stays numpy on the host, like the reference; the T warps
-(``cv2.warpAffine`` on the CPU there, inside the timed region of demo.py) are one HIP launch from the uploaded crops:
-``af_warp_affine_clip_u8`` (csrc/af_align.hip).  With ``device_output=True`` the aligned clip stays in HBM as the uint8
+a 4-unknown least-squares problem on T*5 points and stays on the host, like the reference - in closed form (the normal
+equations of a similarity are diagonal in centred coordinates: ~30 us instead of two SVD-based ``lstsq`` + ``matrix_rank``
+calls; same answer to 1e-12); the T warps (``cv2.warpAffine`` on the CPU there, inside the timed region of demo.py) are one
+HIP launch from the uploaded crops: ``af_warp_affine_clip_u8`` (csrc/af_align.hip).  The crops go through a persistent ring
+of pinned staging buffers (filled by a few copy threads, one asynchronous H2D copy per clip, no allocation and no
+synchronisation per call: round 3).  With ``device_output=True`` the aligned clip stays in HBM as the uint8
 (T, size, size, 3) tensor ``I3D8x8.forward_clips_u8`` consumes - no host round trip between aligner and classifier.
 
 The warp's arithmetic is OpenCV's fixed-point bilinear one, bit-exact against the CPU restatement in oracle/; against
@@ -15,6 +18,9 @@ cv2 itself its parity is unpinned (cv2 is absent from the build image, the refer
 aligned frame).  There is no CPU fallback: without the HIP library the call fails.
 """
 import ctypes as C
+import os
+import threading
+from concurrent.futures import ThreadPoolExecutor
 from typing import Optional, Sequence
 
 import numpy as np
@@ -27,21 +33,28 @@ STD_POINTS_256 = STD_POINTS_317 - np.array([30.0, 60.0])                        
 
 def _nonreflective(src: np.ndarray, dst: np.ndarray):
     """least squares for dst ~ [x y 1] . [[sc -ss] [ss sc] [tx ty]] read backwards (cp2tform's convention,
-    warp_for_xray.py:224-334): solves for the map dst -> src and returns its inverse, the forward 3x3 (row vectors)."""
-    x, y = dst[:, 0:1], dst[:, 1:2]
-    one, zero = np.ones_like(x), np.zeros_like(x)
-    A = np.vstack((np.hstack((x, y, one, zero)), np.hstack((y, -x, zero, one))))
-    b = np.vstack((src[:, 0:1], src[:, 1:2]))
-    if np.linalg.matrix_rank(A) < 4:
+    warp_for_xray.py:224-334): solves for the map dst -> src and returns its inverse, the forward 3x3 (row vectors).
+    The reference calls numpy.linalg.lstsq on the 2N x 4 system  u = sc x + ss y + tx,  v = sc y - ss x + ty  (x, y = dst,
+    u, v = src); in centred coordinates its normal equations are diagonal, so the minimiser is written down directly."""
+    x, y, u, v = dst[:, 0], dst[:, 1], src[:, 0], src[:, 1]
+    xm, ym, um, vm = x.mean(), y.mean(), u.mean(), v.mean()
+    xc, yc, uc, vc = x - xm, y - ym, u - um, v - vm
+    den = float(xc @ xc + yc @ yc)
+    # rank(A) < 4 <=> all target points coincide (numpy.linalg.matrix_rank's verdict in the reference, :262-263)
+    if not den > 1e-20 * (1.0 + float(x @ x + y @ y)):
         raise Exception("cp2tform:twoUniquePointsReq")
-    sc, ss, tx, ty = np.squeeze(np.linalg.lstsq(A, b, rcond=-1)[0])
-    fwd = np.linalg.inv(np.array([[sc, -ss, 0.0], [ss, sc, 0.0], [tx, ty, 1.0]]))
-    fwd[:, 2] = (0.0, 0.0, 1.0)
-    return fwd
+    sc = float(xc @ uc + yc @ vc) / den
+    ss = float(yc @ uc - xc @ vc) / den
+    tx, ty = um - sc * xm - ss * ym, vm - sc * ym + ss * xm
+    # inverse of [[sc, -ss, 0], [ss, sc, 0], [tx, ty, 1]]
+    det = sc * sc + ss * ss
+    a, b = sc / det, ss / det
+    return np.array([[a, b, 0.0], [-b, a, 0.0], [-(tx * a - ty * b), -(tx * b + ty * a), 1.0]])
 
 
 def _apply(trans: np.ndarray, pts: np.ndarray) -> np.ndarray:
-    return (np.hstack((pts, np.ones((pts.shape[0], 1)))) @ trans)[:, :2]
+    """row-vector points (..., 2) through a 3x3 forward matrix"""
+    return pts @ trans[:2, :2] + trans[2, :2]
 
 
 def estimate_batch_transform(all_src_pts, tgt_pts: np.ndarray):
@@ -49,12 +62,53 @@ def estimate_batch_transform(all_src_pts, tgt_pts: np.ndarray):
     findSimilarity (:337-425) the mirrored fit reflects the target array in place, so BOTH residuals are measured against
     the reflected targets - kept, it decides which solution wins."""
     src = np.asarray(all_src_pts, dtype=np.float64).reshape(-1, 2)
-    tgt = np.repeat(np.asarray(tgt_pts, dtype=np.float64)[None], len(all_src_pts), 0).reshape(-1, 2)
+    tgt = np.tile(np.asarray(tgt_pts, dtype=np.float64), (len(all_src_pts), 1))
     plain = _nonreflective(src, tgt)
     tgt[:, 0] *= -1.0
     mirrored = _nonreflective(src, tgt) @ np.diag([-1.0, 1.0, 1.0])
     trans = plain if np.linalg.norm(_apply(plain, src) - tgt) <= np.linalg.norm(_apply(mirrored, src) - tgt) else mirrored
     return trans[:, 0:2].T, trans
+
+
+class _StagingRing:
+    """persistent pinned host buffers + their device twins, used round-robin: a slot is rewritten only after the event
+    recorded behind its last consumer (the warp launch) has completed, so neither the asynchronous copy nor the kernel can
+    see a buffer change under them; `slots` clips may be in flight."""
+
+    def __init__(self, slots: int = 3):
+        self.host = [None] * slots
+        self.dev = [None] * slots
+        self.done = [None] * slots
+        self.next = 0
+        self.lock = threading.Lock()
+
+    def acquire(self, nbytes: int, dev) -> int:
+        with self.lock:
+            k = self.next
+            self.next = (k + 1) % len(self.host)
+        if self.done[k] is not None:
+            self.done[k].synchronize()
+        if self.host[k] is None or self.host[k].numel() < nbytes or self.dev[k].device != dev:
+            cap = max(nbytes + nbytes // 4, 1 << 20)
+            self.host[k] = torch.empty(cap, dtype=torch.uint8, pin_memory=True)
+            self.dev[k] = torch.empty(cap, dtype=torch.uint8, device=dev)
+        return k
+
+
+_COPY_THREADS = max(1, min(8, (os.cpu_count() or 2) // 2))
+_copy_pool = None
+
+
+def _pool():
+    global _copy_pool
+    if _copy_pool is None:
+        _copy_pool = ThreadPoolExecutor(max_workers=_COPY_THREADS, thread_name_prefix="af-align-stage")
+    return _copy_pool
+
+
+def _copy_group(pairs):
+    for dst, im in pairs:
+        np.copyto(dst, im.reshape(-1) if im.flags.c_contiguous else np.ascontiguousarray(im).reshape(-1))
 
 
 class FasterCropAlignXRay:
@@ -68,6 +122,7 @@ class FasterCropAlignXRay:
         self.std_points = STD_POINTS_256 * size / 256.0
         self.return_ldm5 = return_ldm5
         self.device = device
+        self._ring = _StagingRing()
 
     def __call__(self, landmarks, images: Optional[Sequence[np.ndarray]] = None, jitter: bool = False, device_output: bool = False):
         landmarks = [lm[:4] for lm in landmarks]
@@ -82,8 +137,7 @@ class FasterCropAlignXRay:
         if jitter:
             fit_pts += np.random.uniform(-4, 4, fit_pts.shape)
         tfm, trans = estimate_batch_transform(fit_pts, self.std_points)
-        t68 = np.array([_apply(trans, l) for l in l68_c])
-        t5 = np.array([_apply(trans, l) for l in five_c])
+        t68, t5 = _apply(trans, l68_c), _apply(trans, five_c)
         if images is None:
             return (t5, t68) if self.return_ldm5 else t68
         aligned = self.warp_clip(images, diff, int(h), int(w), tfm)
@@ -92,26 +146,55 @@ class FasterCropAlignXRay:
         return (t5, t68, aligned) if self.return_ldm5 else (t68, aligned)
 
     def warp_clip(self, images: Sequence[np.ndarray], diff: np.ndarray, h: int, w: int, tfm: np.ndarray) -> torch.Tensor:
-        """the ``process_single`` loop (:75-88) for the whole clip: upload the crops, one launch per <= 64 frames"""
+        """the ``process_single`` loop (:75-88) for the whole clip: upload the crops, one launch per <= 64 frames.  Everything
+        is enqueued on the current stream and the call returns without synchronising (the staging slot is protected by an
+        event, see _StagingRing); `out` is valid for stream-ordered consumers, `.cpu()` waits for it."""
         dev = self.device or torch.device("cuda", torch.cuda.current_device())
+        dev = torch.device(dev)
+        if dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
         out = torch.empty((len(images), self.image_size, self.image_size, 3), dtype=torch.uint8, device=dev)
         if len(images) == 0:
             return out
         with torch.cuda.device(dev):
-            crops, offs, host = self.stage_crops(images, dev)
+            crops, offs, slot = self.stage_crops_ring(images, dev)
             self.launch_warps(crops, offs, [im.shape for im in images], diff, h, w, tfm, out)
-            torch.cuda.current_stream(dev).synchronize()      # `crops` / `host` must outlive the asynchronous copy and launch
+            ev = torch.cuda.Event()
+            ev.record()
+            self._ring.done[slot] = ev
         return out
 
     @staticmethod
-    def stage_crops(images: Sequence[np.ndarray], dev):
-        """crops -> one pinned host buffer -> one H2D copy; returns (device bytes, per-frame byte offsets, host buffer)"""
+    def _layout(images: Sequence[np.ndarray]):
         offs, total = [], 0
         for im in images:
             if not (isinstance(im, np.ndarray) and im.dtype == np.uint8 and im.ndim == 3 and im.shape[2] == 3):
                 raise AssertionError("aligner: images must be HxWx3 uint8 numpy arrays")
             offs.append(total)
             total += (im.size + 15) // 16 * 16
+        return offs, total
+
+    def stage_crops_ring(self, images: Sequence[np.ndarray], dev):
+        """crops -> a pinned ring slot (copy threads; numpy releases the GIL for these copies) -> one asynchronous H2D copy
+        into the slot's device twin; returns (device bytes, per-frame byte offsets, slot)"""
+        offs, total = self._layout(images)
+        k = self._ring.acquire(total, dev)
+        hv = self._ring.host[k].numpy()
+        pairs = [(hv[o:o + im.size], im) for im, o in zip(images, offs)]
+        nt = min(_COPY_THREADS, len(pairs))
+        if nt > 1 and total >= (1 << 20):
+            list(_pool().map(_copy_group, [pairs[i::nt] for i in range(nt)]))
+        else:
+            _copy_group(pairs)
+        d = self._ring.dev[k]
+        d[:total].copy_(self._ring.host[k][:total], non_blocking=True)
+        return d, offs, k
+
+    @staticmethod
+    def stage_crops(images: Sequence[np.ndarray], dev):
+        """crops -> one fresh pinned host buffer -> one H2D copy; returns (device bytes, per-frame byte offsets, host buffer).
+        (For callers that keep the crops resident, e.g. bench.py --model aligner; __call__ goes through the ring.)"""
+        offs, total = FasterCropAlignXRay._layout(images)
         host = torch.empty(total, dtype=torch.uint8, pin_memory=True)
         hv = host.numpy()
         for im, o in zip(images, offs):

@@ -22,6 +22,7 @@
 //   * pipeline: 3-slot LDS ring, K-steps s+1 and s+2 in flight while step s is multiplied; one raw
 //     s_barrier per K-step; explicit counted s_waitcnt vmcnt (hipcc does not see the DMA loads).
 #include "af_common.h"
+#include <stdlib.h>
 
 namespace af {
 
@@ -60,12 +61,14 @@ struct ConvArgs {
 // KS = 2 splits each stage's K between wave groups 0-3 / 4-7 (used for Cout = 64: every wave then owns a
 // 64x64 sub-tile, halving LDS fragment traffic per MFMA; the two partial sums meet in LDS after the loop).
 // DUAL compiles in the second K segment (projection shortcut accumulated into the same tile).
-template <int DT, int BN, int BM, int WN, int WM, int KS, int NSTAGE, int MINW, bool DUAL, bool SPLITK>
+// BMR < BM: the tile covers BMR output positions (frame-aligned tile counts: 224 rows = 224 tiles for the 50 176 positions
+// of a 16-clip s4 / s5 tensor instead of 196 on 256 CUs); its LDS image keeps BM rows, rows BMR.. are fetched as zeros.
+template <int DT, int BN, int BM, int WN, int WM, int KS, int NSTAGE, int MINW, bool DUAL, bool SPLITK, int BMR>
 __global__ __launch_bounds__(WN * WM * KS * 64, MINW) void conv_igemm_kernel(const ConvArgs a) {
     typedef Elem<DT> E;
     constexpr int EPC = E::EPC;            // elements per 16-byte chunk
     constexpr int ES = 16 / EPC;           // bytes per element
-    constexpr int WTN = BN / WN, WTM = BM / WM;
+    constexpr int WTN = BN / WN, WTM = BMR / WM;
     constexpr int TN = WTN / 16, TM = WTM / 16;
     constexpr int NW = WN * WM * KS;                 // waves per workgroup
     constexpr int GR = NW * 8;                       // tile rows one pass of the workgroup stages (8 lanes per row)
@@ -73,6 +76,7 @@ __global__ __launch_bounds__(WN * WM * KS * 64, MINW) void conv_igemm_kernel(con
     constexpr int PER_WAVE = RW + RX;                // LDS-DMA instructions a wave issues per stage
     constexpr int STAGE_BYTES = (BN + BM) * 128;
     static_assert(NW == 8 && (KS == 1 || KS == 2) && BN % GR == 0 && BM % GR == 0, "8 waves per workgroup");
+    static_assert(BMR <= BM && BMR % (WM * 16) == 0, "real tile rows");
     constexpr bool LEAN = MINW >= 4;
     typedef Mma<DT> MMA;
     static_assert(NSTAGE == 3 || (NSTAGE == 2 && !LEAN && KS == 1), "ring depth of the pipelined loop: 3 or 2 slots");
@@ -98,7 +102,7 @@ __global__ __launch_bounds__(WN * WM * KS * 64, MINW) void conv_igemm_kernel(con
     // The origin is the (padding-shifted) first input element of tile row 0; every other row of the tile lies at a
     // non-negative offset from it (row offsets grow with (n, to, ho, wo), also in the pool-fused row order).
     const int taps = a.kt * a.kh * a.kw;
-    const long long m0 = (long long)tile_m * BM;
+    const long long m0 = (long long)tile_m * BMR;
     auto row_offsets = [&](long long m, long long& off1, long long& off2, unsigned& mask) {
         // tile row -> output position.  With the temporal pool fused, rows are ordered (n, to/2, ho, wo, to%2):
         // the two frames a pool window spans are ADJACENT rows of the tile (the epilogue takes their max)
@@ -134,7 +138,7 @@ __global__ __launch_bounds__(WN * WM * KS * 64, MINW) void conv_igemm_kernel(con
     for (int i = 0; i < RX; ++i) {
         const long long m = m0 + lrow + GR * i;
         xmask[i] = 0; xoff[i] = kOutOfRange; x2off[i] = kOutOfRange;
-        if (m < a.M) {
+        if (m < a.M && (BMR == BM || lrow + GR * i < BMR)) {
             long long o1, o2;
             row_offsets(m, o1, o2, xmask[i]);
             xoff[i] = (unsigned)(o1 - org1) + chunk * 16;       // < 2 GiB (host-checked span)
@@ -379,7 +383,7 @@ __global__ __launch_bounds__(WN * WM * KS * 64, MINW) void conv_igemm_kernel(con
         patch_off = WN * WM * TN * TM * 64 * 4;        // patches live above the reduction buffer
     }
     constexpr int PROW = WTN + 4;                      // patch row stride in floats (pad: conflict-free b128 writes)
-    constexpr int HALVES = TM >= 8 ? 4 : TM >= 2 ? 2 : 1;   // the patch holds a slice of the sub-tile at a time (LDS footprint)
+    constexpr int HALVES = TM % 4 == 0 && TM >= 8 ? 4 : TM % 2 == 0 ? 2 : TM;   // the patch holds a slice of the sub-tile at a time (LDS footprint)
     constexpr int TMH = TM / HALVES, PROWS = TMH * 16;
     float* patch = reinterpret_cast<float*>(smem) + patch_off + wsub * (PROWS * PROW);
     constexpr int LPR = WTN / EPC;                     // lanes per output row (16 bytes each)
@@ -506,22 +510,22 @@ __global__ __launch_bounds__(WN * WM * KS * 64, MINW) void conv_igemm_kernel(con
     }
 }
 
-template <int DT, int BN, int BM, int WN, int WM, int KS, int MINW, bool DUAL, int NSTAGE = 3, bool SPLITK = false>
+template <int DT, int BN, int BM, int WN, int WM, int KS, int MINW, bool DUAL, int NSTAGE = 3, bool SPLITK = false, int BMR = BM>
 static int launch(const ConvArgs& a, hipStream_t stream) {
-    const long long tiles_m = (a.M + BM - 1) / BM;
+    const long long tiles_m = (a.M + BMR - 1) / BMR;
     const long long blocks = tiles_m * a.tiles_n;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return set_error(AF_ERR_ARG, "conv: grid of %lld workgroups", blocks);
     // LDS actually needed: the ring slots this layer's K loop touches, or the epilogue patches
-    constexpr int TMv = BM / WM / 16;
+    constexpr int TMv = BMR / WM / 16;
     constexpr int red_bytes = KS == 2 ? WN * WM * (BN / WN / 16) * TMv * 64 * 16 : 0;
-    constexpr int patch_bytes = red_bytes + WN * WM * ((TMv >= 8 ? TMv / 4 : TMv >= 2 ? TMv / 2 : TMv) * 16) * (BN / WN + 4) * 4;
+    constexpr int patch_bytes = red_bytes + WN * WM * ((TMv % 4 == 0 && TMv >= 8 ? TMv / 4 : TMv % 2 == 0 ? TMv / 2 : 1) * 16) * (BN / WN + 4) * 4;
     const int S = a.kt * a.kh * a.kw * a.kpt + a.kpt2;
     const int slots = (MINW >= 4 && a.ring == 2) ? 2 : NSTAGE;
     const int ring_bytes = (S < slots ? S : slots) * (BN + BM) * 128;
     const int lds = ring_bytes > patch_bytes ? ring_bytes : patch_bytes;
-    AF_SET_MAX_LDS((&conv_igemm_kernel<DT, BN, BM, WN, WM, KS, NSTAGE, MINW, DUAL, SPLITK>),
+    AF_SET_MAX_LDS((&conv_igemm_kernel<DT, BN, BM, WN, WM, KS, NSTAGE, MINW, DUAL, SPLITK, BMR>),
                    NSTAGE * (BN + BM) * 128 > patch_bytes ? NSTAGE * (BN + BM) * 128 : patch_bytes, "conv");
-    hipLaunchKernelGGL((conv_igemm_kernel<DT, BN, BM, WN, WM, KS, NSTAGE, MINW, DUAL, SPLITK>), dim3((unsigned)blocks, SPLITK ? a.ksplit : 1), dim3(WN * WM * KS * 64), lds, stream, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<DT, BN, BM, WN, WM, KS, NSTAGE, MINW, DUAL, SPLITK, BMR>), dim3((unsigned)blocks, SPLITK ? a.ksplit : 1), dim3(WN * WM * KS * 64), lds, stream, a);
     AF_CHECK_LAUNCH("conv_igemm_kernel");
     return AF_OK;
 }
@@ -531,7 +535,7 @@ static int launch(const ConvArgs& a, hipStream_t stream) {
 // output: half-height tiles with a trimmed ring so several workgroups share a CU and overlap each
 // other's load / store phases.
 enum { VAR_128x256 = 0, VAR_64x256 = 1, VAR_128x128 = 2, VAR_64x128 = 3, VAR_C133 = 4, VAR_128x128_R2 = 5, VAR_256x256 = 6,
-       VAR_128x512 = 7, VAR_C311 = 8, VAR_SMALL = 9, VAR_C111 = 10, VAR_C133G = 11, VAR_COUNT = 12 };
+       VAR_128x512 = 7, VAR_C311 = 8, VAR_SMALL = 9, VAR_C111 = 10, VAR_C133G = 11, VAR_256x224 = 12, VAR_COUNT = 13 };
 static const char* const kVariantNames[] = {"conv_igemm<BN=128,BM=256>", "conv_igemm<BN=64,BM=256>",
                                             "conv_igemm<BN=128,BM=128>", "conv_igemm<BN=64,BM=128>",
                                             "conv133_c64<weights in registers>", "conv_igemm<BN=128,BM=128>",
@@ -539,7 +543,8 @@ static const char* const kVariantNames[] = {"conv_igemm<BN=128,BM=256>", "conv_i
                                             "conv311_c64<time-tiled, taps share one LDS image>",
                                             "conv_small<direct-gather MFMA, narrow layers>",
                                             "conv111<persistent stream, weights in registers>",
-                                            "conv133g<frame-resident halo patch, 9 taps share it>"};
+                                            "conv133g<frame-resident halo patch, 9 taps share it>",
+                                            "conv_igemm<BN=256,BM=224>"};
 
 static int pick_variant(int cout, int cin, int taps, int dtype, long long M, int cin2 = 0, int pooled = 0) {
     const int ksteps = (taps * cin + cin2) / (dtype == AF_F32 ? 32 : 64);
@@ -548,9 +553,17 @@ static int pick_variant(int cout, int cin, int taps, int dtype, long long M, int
     if (cout % 256 == 0 && ksteps >= (pooled == 2 ? 4 : cin2 ? 6 : 9)) {
         // 256x256 tiles (128x64 per wave) move a third less L2 -> LDS traffic per MAC, which is what bounds the
         // 128x256 tile; a layer is as slow as its last round of workgroups, so compare whole rounds on the 256 CUs
-        // (measured: one 256x256 tile takes 1.63x the time of a 128x256 tile)
+        // (measured: one 256x256 tile takes 1.63x the time of a 128x256 tile).
+        // 256x224 (64x112 per wave): the positions of the deep stages are multiples of 49 - 224-row tiles are 224 / 448 / 896
+        // workgroups where 256-row tiles are 196 / 392 / 784 (77 % of the CUs in the last round); a 224-row tile costs ~0.89 of
+        // a 256-row one.  AF_IGEMM_224 = 0 / 2 forces never / always (experiments).
+        const char* e224 = getenv("AF_IGEMM_224");
+        const int mode224 = e224 ? atoi(e224) : 1;
         const long long tm = (M + 255) / 256, big = tm * (cout / 256), v0 = tm * (cout / 128);
-        if (big >= 128 && (double)((big + 255) / 256) < 0.615 * (double)((v0 + 255) / 256) + 0.05) return VAR_256x256;
+        const long long b224 = (M + 223) / 224 * (cout / 256);
+        const double c256 = (double)((big + 255) / 256), c224 = 0.89 * (double)((b224 + 255) / 256);
+        const bool take224 = pooled == 0 && mode224 != 0 && (mode224 == 2 || (M % 49 == 0 && c224 < c256 - 0.02));
+        if (big >= 128 && (take224 ? c224 : c256) < 0.615 * (double)((v0 + 255) / 256) + 0.05) return take224 ? VAR_256x224 : VAR_256x256;
     }
     if (cout == 128 && !cin2 && taps >= 9) {
         // the same 128x64-per-wave layout turned on its side for 128-channel layers: 128x512 tiles (1x3x3 layers;
@@ -585,9 +598,9 @@ __global__ void splitk_finish_kernel(const float* ws, int ksplit, long long M, i
 }
 
 // M-rows of a variant's tile
-static int variant_bm(int v) { return v == VAR_128x512 ? 512 : (v == VAR_128x256 || v == VAR_64x256 || v == VAR_256x256) ? 256 : 128; }
+static int variant_bm(int v) { return v == VAR_128x512 ? 512 : v == VAR_256x224 ? 224 : (v == VAR_128x256 || v == VAR_64x256 || v == VAR_256x256) ? 256 : 128; }
 static int variant_bn(int v) {
-    return v == VAR_256x256 ? 256 : (v == VAR_128x256 || v == VAR_128x512 || v == VAR_128x128 || v == VAR_128x128_R2) ? 128 : 64;
+    return (v == VAR_256x256 || v == VAR_256x224) ? 256 : (v == VAR_128x256 || v == VAR_128x512 || v == VAR_128x128 || v == VAR_128x128_R2) ? 128 : 64;
 }
 // split K when the tiles alone leave most CUs idle (one clip, the deep stages): up to 8 K ranges of >= 8 K-steps each whose
 // fp32 partial sums meet in the CALLER's workspace (ksplit * M * Cout floats); 1 = no split
@@ -618,6 +631,7 @@ static int dispatch(ConvArgs& a, hipStream_t stream) {
     if (a.in2) {                                 // projection blocks (64-wide tiles: SlowFast's Fast pathway)
         switch (v) {
             case VAR_256x256: rc = launch<DT, 256, 256, 2, 4, 1, 2, true, 2>(a, stream); break;
+            case VAR_256x224: rc = launch<DT, 256, 256, 4, 2, 1, 2, true, 2, false, 224>(a, stream); break;
             case VAR_128x256: rc = launch<DT, 128, 256, 2, 4, 1, 2, true>(a, stream); break;
             case VAR_64x256: rc = launch<DT, 64, 256, 1, 8, 1, 2, true>(a, stream); break;
             case VAR_128x128:
@@ -627,6 +641,7 @@ static int dispatch(ConvArgs& a, hipStream_t stream) {
     } else if (a.ksplit > 1) {
         switch (v) {
             case VAR_256x256: rc = launch<DT, 256, 256, 2, 4, 1, 2, false, 2, true>(a, stream); break;
+            case VAR_256x224: rc = launch<DT, 256, 256, 4, 2, 1, 2, false, 2, true, 224>(a, stream); break;
             case VAR_128x512: rc = launch<DT, 128, 512, 2, 4, 1, 2, false, 2, true>(a, stream); break;
             case VAR_128x256: rc = launch<DT, 128, 256, 2, 4, 1, 2, false, 3, true>(a, stream); break;
             case VAR_64x256: rc = launch<DT, 64, 256, 1, 8, 1, 2, false, 3, true>(a, stream); break;
@@ -637,6 +652,7 @@ static int dispatch(ConvArgs& a, hipStream_t stream) {
     } else {
         switch (v) {
             case VAR_256x256: rc = launch<DT, 256, 256, 2, 4, 1, 2, false, 2>(a, stream); break;
+            case VAR_256x224: rc = launch<DT, 256, 256, 4, 2, 1, 2, false, 2, false, 224>(a, stream); break;
             case VAR_128x512: rc = launch<DT, 128, 512, 2, 4, 1, 2, false, 2>(a, stream); break;
             case VAR_128x256: rc = launch<DT, 128, 256, 2, 4, 1, 2, false>(a, stream); break;
             case VAR_64x256: rc = launch<DT, 64, 256, 1, 8, 1, 2, false>(a, stream); break;

@@ -231,6 +231,15 @@ def test_kernel_selection_and_workspace_sizing_are_host_logic():
     assert name(s4b(16, 0)).startswith("conv_igemm")                                            # fp32: generic kernel
     assert name(_desc(16, 16, 28, 28, 128, 128, (1, 3, 3), (1, 2, 2), (0, 1, 1))).startswith("conv_igemm")   # stride 2
     assert name(_desc(16, 32, 56, 56, 64, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1))).startswith("conv133_c64")
+    # the long-K `a` convs of s4 (positions = a multiple of 49: 14x14 frames): 224-row tiles = 224 workgroups instead of 196
+    s4a = _desc(16, 16, 14, 14, 1024, 256, (3, 1, 1), (1, 1, 1), (1, 0, 0))
+    assert name(s4a) == "conv_igemm<BN=256,BM=224>"
+    os.environ["AF_IGEMM_224"] = "0"
+    try:
+        assert name(s4a) == "conv_igemm<BN=256,BM=256>"
+    finally:
+        del os.environ["AF_IGEMM_224"]
+    assert name(_desc(16, 16, 16, 16, 1024, 256, (3, 1, 1), (1, 1, 1), (1, 0, 0))) == "conv_igemm<BN=256,BM=256>"   # 65 536 positions
     # split-K scratch: one clip in s4 / s5 splits, a full batch does not
     assert L.af_conv_workspace_bytes(C.byref(s4b(1))) > 0 and L.af_conv_workspace_bytes(C.byref(s4b(16))) == 0
     s5b = _desc(1, 16, 7, 7, 512, 512, (1, 3, 3), (1, 1, 1), (0, 1, 1))
