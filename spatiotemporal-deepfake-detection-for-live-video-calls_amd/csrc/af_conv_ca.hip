@@ -274,21 +274,29 @@ __global__ __launch_bounds__(512, 2) void conv_ca_kernel(const CAArgs a) {
         // ---- a conv: three temporal taps of the slab
         const uint4* ws = smem + (q & 1) * (WBYTES / 16) + frow * 8;
         const uint4* xs = reinterpret_cast<const uint4*>(img) + (wm * 32 + frow) * 8;
+        // the six (tap, k-half) steps, software-pipelined by hand: step s + 1's fragments are read while step s multiplies
+        // (left to hipcc the reads sat right in front of their MFMAs: a chain of LDS latencies, as in conv311)
+        {
+            uint4 af[2][TN], bf[2][TM];
+            auto read_step = [&](uint4 (&fa)[TN], uint4 (&fb)[TM], int step) {
+                const int dt = step >> 1, c = ((step & 1) * 4 + fg) ^ (frow & 7);
 #pragma unroll
-        for (int dt = 0; dt < 3; ++dt)
+                for (int i = 0; i < TN; ++i) fa[i] = ws[(dt * 64 + i * 16) * 8 + c];
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                const int c = (kk * 4 + fg) ^ (frow & 7);
-                uint4 af[TN], bf[TM];
+                for (int j = 0; j < TM; ++j) fb[j] = xs[(dt * P + j * 16) * 8 + c];
+            };
+            read_step(af[0], bf[0], 0);
 #pragma unroll
-                for (int i = 0; i < TN; ++i) af[i] = ws[(dt * 64 + i * 16) * 8 + c];
-#pragma unroll
-                for (int j = 0; j < TM; ++j) bf[j] = xs[(dt * P + j * 16) * 8 + c];
+            for (int step = 0; step < 6; ++step) {
+                if (step + 1 < 6) read_step(af[(step + 1) & 1], bf[(step + 1) & 1], step + 1);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < TN; ++i)
 #pragma unroll
-                    for (int j = 0; j < TM; ++j) Mma<DT>::run(af[i], bf[j], acc[i][j]);
+                    for (int j = 0; j < TM; ++j) Mma<DT>::run(af[step & 1][i], bf[step & 1][j], acc[i][j]);
+                __builtin_amdgcn_sched_barrier(0);
             }
+        }
         if (!last) { ++c_kc; continue; }
 
         // ---- tile finished: BN + ReLU + the one rounding, 8 bytes per lane straight from the accumulators (a 32-KB tile of

@@ -119,13 +119,15 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const StemArgs a) {
 // columns x R CONSECUTIVE OUTPUT ROWS: per dt plane it loads the 2R+5 input rows once and feeds 7R MFMAs from them
 // (R = 8: 21 loads for 56 MFMAs instead of 56), the 7 weight fragments of the plane coming from an LDS image of all
 // kt slices that is loaded once per workgroup.
-template <int DT, int R>
+// KT > 0 (compile-time temporal taps): the 21 input rows of plane dt + 1 are fetched while plane dt multiplies (two register
+// sets; left in one loop hipcc issued every plane's loads right in front of its MFMAs: the full global latency per plane).
+template <int DT, int R, int KT>
 __global__ __launch_bounds__(256) void stem_rows_kernel(const StemArgs a, int tiles_w, int hblocks, long long units) {
     typedef Elem<DT> E;
     constexpr int EPC = E::EPC, ES = 16 / EPC, NCH = 4, PIXB = 4 * ES, NR = 2 * R + 5;
     static_assert(EPC == 8, "16-bit types only (one 16-byte chunk per lane and K-row)");
     extern __shared__ uint4 wlds[];                      // [kt][kh][NCH][16]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int frow = lane & 15, fg = lane >> 4;
     const int wchunks = a.kt * a.kh * NCH * 16;
     for (int i = tid; i < wchunks; i += 256) wlds[i] = reinterpret_cast<const uint4*>(a.w)[i];
@@ -140,23 +142,44 @@ __global__ __launch_bounds__(256) void stem_rows_kernel(const StemArgs a, int ti
     const bool col_ok = wo < a.Wo;
     if (!col_ok) wo = a.Wo - 1;                          // clamp: loads stay inside the row, result never stored
     const long long row_bytes = (long long)a.Wp * PIXB, plane_bytes = row_bytes * a.Hp;
-    const char* base = a.in + ((((n * a.Tp + to) * a.Hp + 2 * ho0) * a.Wp) + 2 * wo) * PIXB + fg * 16;
+    // wave-uniform row base (scalar registers) + one per-lane 32-bit offset: no 64-bit address VALU per load
+    const char* ubase = a.in + (((n * a.Tp + to) * a.Hp + 2 * ho0) * a.Wp) * PIXB;
+    const unsigned loff = (unsigned)(2 * wo * PIXB + fg * 16);
     const int rmax = a.Hp - 1 - 2 * ho0;                 // last input row that exists below the block's first one
 
     f32x4 acc[R];
 #pragma unroll
     for (int j = 0; j < R; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int dt = 0; dt < a.kt; ++dt) {
-        uint4 bx[NR], af[7];
+    auto load_plane = [&](uint4 (&bx)[NR], int dt) {
 #pragma unroll
         for (int r = 0; r < NR; ++r)
-            bx[r] = *reinterpret_cast<const uint4*>(base + dt * plane_bytes + (long long)(r < rmax ? r : rmax) * row_bytes);
+            bx[r] = *reinterpret_cast<const uint4*>(ubase + dt * plane_bytes + (long long)(r < rmax ? r : rmax) * row_bytes + loff);
+    };
+    auto mul_plane = [&](const uint4 (&bx)[NR], int dt) {
+        uint4 af[7];
 #pragma unroll
         for (int dh = 0; dh < 7; ++dh) af[dh] = wlds[((dt * 7 + dh) * NCH + fg) * 16 + frow];
 #pragma unroll
         for (int j = 0; j < R; ++j)
 #pragma unroll
             for (int dh = 0; dh < 7; ++dh) Mma<DT>::run(af[dh], bx[2 * j + dh], acc[j]);
+    };
+    if (KT > 0) {
+        uint4 b0[NR], b1[NR];
+        load_plane(b0, 0);
+#pragma unroll
+        for (int dt = 0; dt < KT; ++dt) {
+            if (dt + 1 < KT) load_plane((dt & 1) ? b0 : b1, dt + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mul_plane((dt & 1) ? b1 : b0, dt);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+        for (int dt = 0; dt < a.kt; ++dt) {
+            uint4 bx[NR];
+            load_plane(bx, dt);
+            mul_plane(bx, dt);
+        }
     }
     const int ch = fg * 4;
     if (!col_ok || ch >= a.cout) return;
@@ -178,7 +201,8 @@ static int launch_stem_rows(const StemArgs& a, hipStream_t stream) {
     const long long n_to = a.M / ((long long)a.Ho * a.Wo), units = n_to * hblocks * tiles_w, blocks = (units + 3) / 4;
     if (blocks > 0x7fffffffLL) return set_error(AF_ERR_ARG, "stem: grid too large");
     const int lds = a.kt * a.kh * 4 * 16 * 16;
-    hipLaunchKernelGGL((stem_rows_kernel<DT, R>), dim3((unsigned)blocks), dim3(256), lds, stream, a, tiles_w, hblocks, units);
+    if (a.kt == 5) hipLaunchKernelGGL((stem_rows_kernel<DT, R, 5>), dim3((unsigned)blocks), dim3(256), lds, stream, a, tiles_w, hblocks, units);
+    else hipLaunchKernelGGL((stem_rows_kernel<DT, R, 0>), dim3((unsigned)blocks), dim3(256), lds, stream, a, tiles_w, hblocks, units);
     AF_CHECK_LAUNCH("stem_rows_kernel");
     return AF_OK;
 }

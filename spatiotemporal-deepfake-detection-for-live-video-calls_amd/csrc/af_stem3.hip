@@ -36,7 +36,14 @@ struct Stem3Args {
 // PW: the image is at most 7 column tiles wide (224 x 224: 112 columns), so wave 7 has no MFMA work - it becomes the
 // POOLING wave: the horizontal 3-max / stride 2 and the store of row pair j run there while waves 0-6 already multiply
 // pair j + 1 (two LDS lines, ONE workgroup barrier per pair instead of two, the pooling off the critical path).
-template <int DT, int KT, bool PW>
+// Round 3: the MFMA loop is software-pipelined by hand.  hipcc had scheduled it as  2 weight reads -> wait -> 2 MFMAs -> wait ->
+// 2 MFMAs  (a chain of LDS latencies: 57 % MFMA issue on the two-wave SIMDs), read every fragment offset from an LDS table in
+// front of its load (an lgkmcnt(0) stall per group) and drained vmcnt(0) at every row-pair boundary to copy the prefetched
+// group into place.  Now: the four weight fragments of block b + 1 are read while block b multiplies (two register sets,
+// sched_barrier-pinned; the reads of the next pair's block 0 ride under the last block), fragment offsets live in registers,
+// and the activation groups alternate between two static register sets with an EVEN number of groups per pair, so the
+// group prefetched for the next pair is already where that pair expects it - no copy, no drain.
+template <int DT, int KT, bool PW, int GB>
 __global__ __launch_bounds__(512, 2) void stem3_pool_kernel(const Stem3Args a) {
     typedef Elem<DT> E;
     typedef typename E::type elem_t;
@@ -44,8 +51,8 @@ __global__ __launch_bounds__(512, 2) void stem3_pool_kernel(const Stem3Args a) {
     constexpr int COUT = 64, TN = 4;
     constexpr int NF = KT * 7 * 3;                             // 16-byte fragments of the kernel
     constexpr int NBLK = (NF + 3) / 4;                         // MFMA K-blocks
-    constexpr int GB = 6;                                      // blocks per prefetch group
-    constexpr int NGRP = (NBLK + GB - 1) / GB;
+    constexpr int NGRP = (NBLK + GB - 1) / GB;                 // prefetch groups of GB blocks per row pair
+    static_assert(NGRP % 2 == 0 || NGRP == 1, "an even number of groups: the two activation register sets alternate");
 
     extern __shared__ uint4 smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -56,27 +63,46 @@ __global__ __launch_bounds__(512, 2) void stem3_pool_kernel(const Stem3Args a) {
     elem_t* line = reinterpret_cast<elem_t*>(smem + wchunks);  // [Wo_tiles*16][64] vertically reduced conv row
     const int ncol_tiles = (a.Wo + 15) >> 4;                   // <= 8 (host-checked)
     const int line_elems = ncol_tiles * 16 * COUT;
-    int* ftab = reinterpret_cast<int*>(line + (PW ? 2 : 1) * line_elems);  // [NBLK][4] fragment byte offsets
     const bool active = wave < ncol_tiles;
+    // BN scale / shift in LDS: a global load in the epilogue would be waited for with vmcnt(0), i.e. together with the
+    // activation group already prefetched for the next row pair
+    float* bn = reinterpret_cast<float*>(line + (PW ? 2 : 1) * line_elems);     // [2][64]
 
     const uint4* wsrc = reinterpret_cast<const uint4*>(a.w);
     for (int i = tid; i < wchunks; i += 512) wl[i] = wsrc[i];
+    if (tid < 2 * COUT) bn[tid] = tid < COUT ? a.scale[tid] : a.shift[tid - COUT];
 
     const int plane_bytes = a.row_bytes * a.Hp;                // < 2^31 (host-checked)
-    // byte offset of fragment f = 4 blk + g = (dt, dh, j) from (frame t, row 4j, pixel 2 wo): a table in LDS (27 registers
-    // per lane otherwise), read once per load
-    if (tid < NBLK * 4) {
-        int f = tid;
-        if (f > NF - 1) f = NF - 1;                            // beyond the kernel: any valid address (zero weights)
-        const int dt = f / 21, r = f - dt * 21, dh = r / 3, jj = r - dh * 3;
-        ftab[tid] = dt * plane_bytes + dh * a.row_bytes + jj * 16;
-    }
     int wo = wave * 16 + frow;
     if (wo > a.Wo - 1) wo = a.Wo - 1;                          // clamp: loads stay inside the row, result discarded
-    const int lane_off = wo * 12;                              // pixel 2 wo, 6 bytes per pixel
+    // byte offset of this lane's fragment of every block: fragment f = 4 blk + g = (dt, dh, j) from (frame t, row 4j, pixel
+    // 2 wo at 6 bytes per pixel); NBLK registers per lane
+    int fo_tab[NBLK];
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b) {
+        int f = b * 4 + fg;
+        if (f > NF - 1) f = NF - 1;                            // beyond the kernel: any valid address (zero weights)
+        const int dt = f / 21, r = f - dt * 21, dh = r / 3, jj = r - dh * 3;
+        fo_tab[b] = wo * 12 + dt * plane_bytes + dh * a.row_bytes + jj * 16;
+    }
     const int pair_bytes = 2 * a.row_bytes;                    // conv row 2j+1 starts two input rows below conv row 2j
+    // weight fragments of block b (one per channel tile) from the LDS image
+    auto read_a = [&](uint4 (&d)[TN], int b) {
+        const uint4* wrow = wl + (b * 4 + fg) * COUT + frow;
+#pragma unroll
+        for (int i = 0; i < TN; ++i) d[i] = wrow[i * 16];
+    };
 
-    for (int unit = blockIdx.x; unit < a.frames * a.bands; unit += gridDim.x) {
+    // units -> workgroups, XCD-contiguous (placement is a speed matter only): workgroups b and b + 8 share an XCD and its L2,
+    // so XCD x takes the x-th eighth of the units - at 16 clips two whole clips, whose 32 frames its 32 CUs convolve at the same
+    // time: every input plane then enters that L2 once instead of once per temporal tap on five different XCDs
+    const int total_units = a.frames * a.bands;
+    const bool xcd_map = (gridDim.x & 7) == 0;
+    const int upx = (total_units + 7) >> 3;
+    const int u_begin = xcd_map ? (int)(blockIdx.x & 7) * upx + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int u_end = xcd_map ? (((int)(blockIdx.x & 7) + 1) * upx < total_units ? ((int)(blockIdx.x & 7) + 1) * upx : total_units) : total_units;
+    const int u_step = xcd_map ? (int)(gridDim.x >> 3) : (int)gridDim.x;
+    for (int unit = u_begin; unit < u_end; unit += u_step) {
         const int frame = unit / a.bands, band = unit - frame * a.bands;
         const int n = frame / a.To, to = frame - n * a.To;
         const int j_begin = band * a.band_rows, j_end = (j_begin + a.band_rows < a.Hq) ? j_begin + a.band_rows : a.Hq;
@@ -88,20 +114,21 @@ __global__ __launch_bounds__(512, 2) void stem3_pool_kernel(const Stem3Args a) {
         __syncthreads();                                       // weights visible (first unit) / line free
 
         // fragments of one group of blocks, both conv rows; the next group is fetched while this one multiplies
-        uint4 bx[GB][2], nx[GB][2];
+        uint4 xs[2][GB][2];
         auto load_group = [&](uint4 (&dst)[GB][2], int jrow, int grp) {
-            const char* rb = fin + (long long)(4 * jrow) * a.row_bytes;                    // uniform
+            const char* rb0 = fin + (long long)(4 * jrow) * a.row_bytes;                   // uniform
+            const char* rb1 = rb0 + pair_bytes;
 #pragma unroll
             for (int k = 0; k < GB; ++k) {
                 const int b = grp * GB + k;
                 if (b < NBLK) {
-                    const int fo = lane_off + ftab[b * 4 + fg];
-                    dst[k][0] = *reinterpret_cast<const uint4*>(rb + (unsigned)fo);
-                    dst[k][1] = *reinterpret_cast<const uint4*>(rb + (unsigned)(fo + pair_bytes));
+                    dst[k][0] = *reinterpret_cast<const uint4*>(rb0 + (unsigned)fo_tab[b]);
+                    dst[k][1] = *reinterpret_cast<const uint4*>(rb1 + (unsigned)fo_tab[b]);
                 }
             }
         };
-        if (active) load_group(bx, j_first, 0);
+        uint4 afc[TN], afn[TN];
+        if (active) { load_group(xs[0], j_first, 0); read_a(afc, 0); }
 
         for (int j = j_first; j < j_end; ++j) {
             f32x4 acc[2][TN];
@@ -112,28 +139,27 @@ __global__ __launch_bounds__(512, 2) void stem3_pool_kernel(const Stem3Args a) {
             if (active) {
 #pragma unroll
                 for (int grp = 0; grp < NGRP; ++grp) {
-                    const bool more = grp + 1 < NGRP || j + 1 < j_end;
-                    if (more) {
-                        if (grp + 1 < NGRP) load_group(nx, j, grp + 1);
-                        else load_group(nx, j + 1, 0);
-                    }
+                    // the next group (of the next pair after the last one) goes into the other register set
+                    // (unconditionally - behind a branch hipcc's vmcnt counts for the last blocks assume the shorter path and
+                    // drain the prefetch; the last pair of a unit re-fetches its own group 0 and drops it)
+                    if (grp + 1 < NGRP) load_group(xs[(grp + 1) & 1], j, grp + 1);
+                    else load_group(xs[(grp + 1) & 1], j + 1 < j_end ? j + 1 : j, 0);
                     __builtin_amdgcn_sched_barrier(0);         // keep the loads AHEAD of this group's MFMAs
 #pragma unroll
                     for (int k = 0; k < GB; ++k) {
                         const int b = grp * GB + k;
                         if (b < NBLK) {
-                            const uint4* wrow = wl + (b * 4 + fg) * COUT + frow;
+                            read_a(afn, b + 1 < NBLK ? b + 1 : 0);         // next block's weights under this block's MFMAs
+                            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                             for (int i = 0; i < TN; ++i) {
-                                const uint4 af = wrow[i * 16];
-                                Mma<DT>::run(af, bx[k][0], acc[0][i]);
-                                Mma<DT>::run(af, bx[k][1], acc[1][i]);
+                                Mma<DT>::run(afc[i], xs[grp & 1][k][0], acc[0][i]);
+                                Mma<DT>::run(afc[i], xs[grp & 1][k][1], acc[1][i]);
                             }
-                        }
-                    }
-                    if (more) {
+                            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (int k = 0; k < GB; ++k) { bx[k][0] = nx[k][0]; bx[k][1] = nx[k][1]; }
+                            for (int i = 0; i < TN; ++i) afc[i] = afn[i];
+                        }
                     }
                 }
             }
@@ -141,8 +167,8 @@ __global__ __launch_bounds__(512, 2) void stem3_pool_kernel(const Stem3Args a) {
             const bool odd_ok = 2 * j + 1 < a.Ho;
 #pragma unroll
             for (int i = 0; i < TN; ++i) {
-                const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + i * 16 + fg * 4);
-                const f32x4 sf = *reinterpret_cast<const f32x4*>(a.shift + i * 16 + fg * 4);
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(bn + i * 16 + fg * 4);
+                const f32x4 sf = *reinterpret_cast<const f32x4*>(bn + COUT + i * 16 + fg * 4);
                 f32x4 v0 = acc[0][i] * sc + sf, v1 = acc[1][i] * sc + sf;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -244,11 +270,13 @@ static inline int rgb3_row_bytes(int w) { return ((w + AF_STEM_PAD_W_TOTAL) * 6 
 template <int DT, int KT, bool PW>
 static int launch_stem3_pw(const Stem3Args& a, hipStream_t stream) {
     constexpr int NBLK = (KT * 21 + 3) / 4;
-    const int lds = NBLK * 4 * 64 * 16 + (PW ? 2 : 1) * ((a.Wo + 15) / 16) * 16 * 64 * 2 + NBLK * 4 * 4;
+    // blocks per prefetch group: an even number of groups per row pair (27 blocks: 6 x 5; 16: 4 x 4; 6: 2 x 3; register budget: 2 x GB x 8 for the two sets)
+    constexpr int GB = KT == 5 ? 5 : KT == 3 ? 4 : 3;
+    const int lds = NBLK * 4 * 64 * 16 + (PW ? 2 : 1) * ((a.Wo + 15) / 16) * 16 * 64 * 2 + 2 * 64 * 4;
     if (lds > 160 * 1024) return set_error(AF_ERR_ARG, "stem3_pool: %d bytes of LDS needed", lds);
-    AF_SET_MAX_LDS((&stem3_pool_kernel<DT, KT, PW>), 160 * 1024, "stem3_pool");
+    AF_SET_MAX_LDS((&stem3_pool_kernel<DT, KT, PW, GB>), 160 * 1024, "stem3_pool");
     const int cus = device_cus(), units = a.frames * a.bands;
-    hipLaunchKernelGGL((stem3_pool_kernel<DT, KT, PW>), dim3(units < cus ? units : cus), dim3(512), lds, stream, a);
+    hipLaunchKernelGGL((stem3_pool_kernel<DT, KT, PW, GB>), dim3(units < cus ? units : cus), dim3(512), lds, stream, a);
     AF_CHECK_LAUNCH("stem3_pool_kernel");
     return AF_OK;
 }
