@@ -66,7 +66,7 @@ __global__ __launch_bounds__(512, 2) void stem3_pool_kernel(const Stem3Args a) {
     const bool active = wave < ncol_tiles;
     // BN scale / shift in LDS: a global load in the epilogue would be waited for with vmcnt(0), i.e. together with the
     // activation group already prefetched for the next row pair
-    float* bn = reinterpret_cast<float*>(line + (PW ? 2 : 1) * line_elems);     // [2][64]
+    float* bn = reinterpret_cast<float*>(line + (PW ? 3 : 1) * line_elems);     // [2][64]
 
     const uint4* wsrc = reinterpret_cast<const uint4*>(a.w);
     for (int i = tid; i < wchunks; i += 512) wl[i] = wsrc[i];
@@ -129,41 +129,42 @@ __global__ __launch_bounds__(512, 2) void stem3_pool_kernel(const Stem3Args a) {
         };
         uint4 afc[TN], afn[TN];
         if (active) { load_group(xs[0], j_first, 0); read_a(afc, 0); }
+        f32x4 acc[2][TN];
 
-        for (int j = j_first; j < j_end; ++j) {
-            f32x4 acc[2][TN];
+        // the K loop of one row pair (accumulators zeroed first)
+        auto mfma_pair = [&](int j) {
 #pragma unroll
             for (int r = 0; r < 2; ++r)
 #pragma unroll
                 for (int i = 0; i < TN; ++i) acc[r][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (active) {
 #pragma unroll
-                for (int grp = 0; grp < NGRP; ++grp) {
-                    // the next group (of the next pair after the last one) goes into the other register set
-                    // (unconditionally - behind a branch hipcc's vmcnt counts for the last blocks assume the shorter path and
-                    // drain the prefetch; the last pair of a unit re-fetches its own group 0 and drops it)
-                    if (grp + 1 < NGRP) load_group(xs[(grp + 1) & 1], j, grp + 1);
-                    else load_group(xs[(grp + 1) & 1], j + 1 < j_end ? j + 1 : j, 0);
-                    __builtin_amdgcn_sched_barrier(0);         // keep the loads AHEAD of this group's MFMAs
+            for (int grp = 0; grp < NGRP; ++grp) {
+                // the next group (of the next pair after the last one) goes into the other register set
+                // (unconditionally - behind a branch hipcc's vmcnt counts for the last blocks assume the shorter path and
+                // drain the prefetch; the last pair of a unit re-fetches its own group 0 and drops it)
+                if (grp + 1 < NGRP) load_group(xs[(grp + 1) & 1], j, grp + 1);
+                else load_group(xs[(grp + 1) & 1], j + 1 < j_end ? j + 1 : j, 0);
+                __builtin_amdgcn_sched_barrier(0);             // keep the loads AHEAD of this group's MFMAs
 #pragma unroll
-                    for (int k = 0; k < GB; ++k) {
-                        const int b = grp * GB + k;
-                        if (b < NBLK) {
-                            read_a(afn, b + 1 < NBLK ? b + 1 : 0);         // next block's weights under this block's MFMAs
-                            __builtin_amdgcn_sched_barrier(0);
+                for (int k = 0; k < GB; ++k) {
+                    const int b = grp * GB + k;
+                    if (b < NBLK) {
+                        read_a(afn, b + 1 < NBLK ? b + 1 : 0);             // next block's weights under this block's MFMAs
+                        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                            for (int i = 0; i < TN; ++i) {
-                                Mma<DT>::run(afc[i], xs[grp & 1][k][0], acc[0][i]);
-                                Mma<DT>::run(afc[i], xs[grp & 1][k][1], acc[1][i]);
-                            }
-                            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                            for (int i = 0; i < TN; ++i) afc[i] = afn[i];
+                        for (int i = 0; i < TN; ++i) {
+                            Mma<DT>::run(afc[i], xs[grp & 1][k][0], acc[0][i]);
+                            Mma<DT>::run(afc[i], xs[grp & 1][k][1], acc[1][i]);
                         }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int i = 0; i < TN; ++i) afc[i] = afn[i];
                     }
                 }
             }
-            // BN + ReLU, vertical 3-max (rows 2j-1, 2j, 2j+1), keep the odd row for the next pair
+        };
+        // BN + ReLU, vertical 3-max (rows 2j-1, 2j, 2j+1), keep the odd row for the next pair; the reduced row -> `dst` line
+        auto epilogue = [&](int j, elem_t* dst) {
             const bool odd_ok = 2 * j + 1 < a.Ho;
 #pragma unroll
             for (int i = 0; i < TN; ++i) {
@@ -178,19 +179,15 @@ __global__ __launch_bounds__(512, 2) void stem3_pool_kernel(const Stem3Args a) {
                     prev[i][e] = v1[e];
                     v0[e] = m;
                 }
-                if (active) {
-                    typedef elem_t e4 __attribute__((ext_vector_type(4)));
-                    e4 o;
-                    o[0] = E::from_f32(v0[0]); o[1] = E::from_f32(v0[1]); o[2] = E::from_f32(v0[2]); o[3] = E::from_f32(v0[3]);
-                    *reinterpret_cast<e4*>(line + (PW ? (j & 1) * line_elems : 0) + (wave * 16 + frow) * COUT + i * 16 + fg * 4) = o;
-                }
+                typedef elem_t e4 __attribute__((ext_vector_type(4)));
+                e4 o;
+                o[0] = E::from_f32(v0[0]); o[1] = E::from_f32(v0[1]); o[2] = E::from_f32(v0[2]); o[3] = E::from_f32(v0[3]);
+                *reinterpret_cast<e4*>(dst + (wave * 16 + frow) * COUT + i * 16 + fg * 4) = o;
             }
-            __syncthreads();
-            // horizontal 3-max, stride 2: pooled col q <- conv cols 2q-1, 2q, 2q+1; 8 channels (16 B) per thread
-            // (PW: by wave 7 alone, from the line of this pair, under the other waves' next pair)
-            const elem_t* pline = line + (PW ? (j & 1) * line_elems : 0);
-            const int pstart = PW ? (wave == 7 ? lane : a.Wq * 8) : tid, pstep = PW ? 64 : 512;
-            for (int idx = pstart; idx < (j >= j_begin ? a.Wq * 8 : 0); idx += pstep) {
+        };
+        // horizontal 3-max, stride 2: pooled col q <- conv cols 2q-1, 2q, 2q+1; 8 channels (16 B) per thread -> output row j
+        auto pool_row = [&](int j, const elem_t* pline, int pstart, int pstep) {
+            for (int idx = pstart; idx < a.Wq * 8; idx += pstep) {
                 const int q = idx >> 3, ch = (idx & 7) * 8;
                 float m[8];
 #pragma unroll
@@ -211,7 +208,36 @@ __global__ __launch_bounds__(512, 2) void stem3_pool_kernel(const Stem3Args a) {
                 for (int e = 0; e < 8; ++e) oe[e] = E::from_f32(m[e]);
                 *reinterpret_cast<uint4*>(a.out + ((((long long)n * a.To + to) * a.Hq + j) * a.Wq + q) * (COUT * 2) + ch * 2) = o;
             }
-            if (!PW) __syncthreads();                          // line may be overwritten by the next row pair
+        };
+
+        if (PW) {
+            // Pooling-wave form, STAGGERED (round 3).  The two MFMA waves of a SIMD ran in lockstep - both in their K loop, then
+            // both in their epilogue (~200 VALU instructions each with the matrix pipe idle), then the barrier.  Waves 4-6 (the
+            // second wave of SIMDs 0-2) now defer a pair's epilogue to the start of the next interval: while waves 0-3 multiply
+            // pair j, waves 4-6 finish pair j - 1 and then multiply pair j under the epilogue of waves 0-3 - matrix beside vector
+            // on every SIMD.  A row pair's line is therefore complete one barrier later (three line buffers): in interval it,
+            // early waves write line it % 3, late waves line (it - 1) % 3, and wave 7 pools line (it - 2) % 3.  One barrier per
+            // interval for everybody, npairs + 2 intervals per unit.
+            const bool late = wave >= 4;
+            const int npairs = j_end - j_first;
+            for (int it = 0; it < npairs + 2; ++it) {
+                const int j = j_first + it;
+                if (active) {                                  // (one K-loop call site: two inlined copies cost 68 spilled registers)
+                    if (late && it >= 1 && it <= npairs) epilogue(j - 1, line + ((it + 2) % 3) * line_elems);
+                    if (it < npairs) mfma_pair(j);
+                    if (!late && it < npairs) epilogue(j, line + (it % 3) * line_elems);
+                } else if (wave == 7 && it >= 2 && j - 2 >= j_begin) {
+                    pool_row(j - 2, line + ((it + 1) % 3) * line_elems, lane, 64);
+                }
+                __syncthreads();
+            }
+        } else {
+            for (int j = j_first; j < j_end; ++j) {
+                if (active) { mfma_pair(j); epilogue(j, line); }
+                __syncthreads();
+                if (j >= j_begin) pool_row(j, line, tid, 512);
+                __syncthreads();                               // line may be overwritten by the next row pair
+            }
         }
     }
 }
@@ -272,7 +298,7 @@ static int launch_stem3_pw(const Stem3Args& a, hipStream_t stream) {
     constexpr int NBLK = (KT * 21 + 3) / 4;
     // blocks per prefetch group: an even number of groups per row pair (27 blocks: 6 x 5; 16: 4 x 4; 6: 2 x 3; register budget: 2 x GB x 8 for the two sets)
     constexpr int GB = KT == 5 ? 5 : KT == 3 ? 4 : 3;
-    const int lds = NBLK * 4 * 64 * 16 + (PW ? 2 : 1) * ((a.Wo + 15) / 16) * 16 * 64 * 2 + 2 * 64 * 4;
+    const int lds = NBLK * 4 * 64 * 16 + (PW ? 3 : 1) * ((a.Wo + 15) / 16) * 16 * 64 * 2 + 2 * 64 * 4;
     if (lds > 160 * 1024) return set_error(AF_ERR_ARG, "stem3_pool: %d bytes of LDS needed", lds);
     AF_SET_MAX_LDS((&stem3_pool_kernel<DT, KT, PW, GB>), 160 * 1024, "stem3_pool");
     const int cus = device_cus(), units = a.frames * a.bands;
