@@ -550,9 +550,7 @@ static int pick_variant(int cout, int cin, int taps, int dtype, long long M, int
     const int ksteps = (taps * cin + cin2) / (dtype == AF_F32 ? 32 : 64);
     const bool wide = cout % 128 == 0, short_k = ksteps <= 3;
     // (with the 2x2 pool fused only a quarter of the output is written: such a layer is MFMA-bound from 4 K-steps on)
-    const char* ebk = getenv("AF_IGEMM_BIGK");                 // experiments: K-steps from which a plain layer takes the 256-row tiles
-    const int bigk = ebk ? atoi(ebk) : 9;
-    if (cout % 256 == 0 && ksteps >= (pooled == 2 ? 4 : cin2 ? 6 : bigk)) {
+    if (cout % 256 == 0 && ksteps >= (pooled == 2 ? 4 : cin2 ? 6 : 9)) {
         // 256x256 tiles (128x64 per wave) move a third less L2 -> LDS traffic per MAC, which is what bounds the
         // 128x256 tile; a layer is as slow as its last round of workgroups, so compare whole rounds on the 256 CUs
         // (measured: one 256x256 tile takes 1.63x the time of a 128x256 tile).

@@ -223,7 +223,10 @@ static int launch_c133(C133Args& a, hipStream_t stream) {
 bool conv133_applies(const af_conv_desc* d, const void* residual, int out_ld) {
     return d->dtype != AF_F32 && d->cin == 64 && d->cout == 64 && d->kt == 1 && d->kh == 3 && d->kw == 3 &&
            d->st == 1 && d->sh == 1 && d->sw == 1 && d->pt == 0 && d->ph == 1 && d->pw == 1 && d->relu && !d->tpool &&
-           residual == nullptr && (out_ld == 0 || out_ld == 64) && 4 * (d->w + 2) <= 256;
+           residual == nullptr && (out_ld == 0 || out_ld == 64) && 4 * (d->w + 2) <= 256 &&
+           // a strip is 4 x (W + 2) positions of the 256 every workgroup multiplies: narrow frames (SlowFast's Fast pathway in
+           // s5: 7 x 7) would run at 14 % and took 2.4x the generic kernel's time
+           4 * (d->w + 2) >= 112;
 }
 
 int conv133_run(const af_conv_desc* d, const void* in, const void* w_packed, const float* scale, const float* shift,

@@ -188,6 +188,10 @@ CONV_CASES = [
     ("3x1x1", 256, 64, (3, 1, 1), (1, 1, 1), (1, 0, 0), (1, 5, 6, 7), True, False),
     ("1x3x3", 64, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), (2, 2, 13, 12), True, False),
     ("1x3x3_s2", 128, 128, (1, 3, 3), (1, 2, 2), (0, 1, 1), (1, 3, 14, 15), True, False),
+    # the weights-in-registers 64 -> 64 kernel (s2 `b` convs) at its own frame size and on a ragged 30 x 27 frame (7.5 strips
+    # of 4 rows); narrower frames take the generic kernel (case "1x3x3" above)
+    ("c64_1x3x3_56x56", 64, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 5, 56, 56), True, False),
+    ("c64_1x3x3_30x27", 64, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), (2, 3, 30, 27), True, False),
     ("3x3x3_synthetic", 64, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 4, 9, 10), True, False),
     ("5x1x1_t_stride8", 64, 128, (5, 1, 1), (8, 1, 1), (2, 0, 0), (1, 32, 4, 5), True, False),
     ("big_m_tail", 64, 64, (1, 1, 1), (1, 1, 1), (0, 0, 0), (3, 7, 17, 19), False, False),
@@ -245,7 +249,8 @@ CONV_CASES = [
     ("halo333_64to128_28x28", 64, 128, (3, 3, 3), (1, 1, 1), (1, 1, 1), (2, 48, 28, 28), True, False),
     ("halo333_128to256_14x14", 128, 256, (3, 3, 3), (1, 1, 1), (1, 1, 1), (2, 100, 14, 14), True, False),
 ]
-EXPECT_VARIANT = {"tile256_1x3x3_res": 6, "tile256_ragged_m": 6, "tile224_1x3x3_res": 12, "tile224_ragged_m": 12,
+EXPECT_VARIANT = {"c64_1x3x3_56x56": {"f16": 4, "bf16": 4}, "c64_1x3x3_30x27": {"f16": 4, "bf16": 4}, "1x3x3": {"f16": 3, "bf16": 3},
+                  "tile256_1x3x3_res": 6, "tile256_ragged_m": 6, "tile224_1x3x3_res": 12, "tile224_ragged_m": 12,
                   "tile224_3x1x1_1024to256": {"f16": 12, "bf16": 12}, "tile224_1x1x1_1024to256_res": {"f16": 12, "bf16": 12}, "tile512_1x3x3_res": 7, "tile512_ragged_m": 7,
                   "t311_64to64_T32": 8, "t311_256to64_T16": 8, "t311_256to64_T32_many": 8,
                   "t311_256to128_T16": {"f32": 3, "f16": 8, "bf16": 8},
