@@ -118,6 +118,10 @@ def roofline_report(eng, args, line, reps=5):
             side = op.conv3.cin if op.in3 else cc_.cout
             eng_bytes[i] = es * (pos * (cc_.cin + side + cc_.cout + ca.cout) + cc_.cout * (cc_.cin + (op.conv3.cin if op.in3 else 0))
                                  + ca.cout * ca.cin * 3)
+        elif op.kind == _lib.AF_OP_BLOCK_ABC:            # trunk in + trunk out + the three weights; a and b stay on chip
+            ca, cb, cc_ = op.conv, op.conv2, op.conv3
+            pos = ca.n * ca.t * ca.h * ca.w
+            eng_bytes[i] = es * (pos * (ca.cin + cc_.cout) + ca.cout * ca.cin * ca.kt + cb.cout * cb.cin * 9 + cc_.cout * cc_.cin)
         elif op.kind == _lib.AF_OP_CONV_BC:              # b input + c output + residual + both weights; the b output stays on chip
             cb, cc_ = op.conv, op.conv2
             pos = cb.n * cb.to * cb.ho * cb.wo
@@ -152,6 +156,8 @@ def roofline_report(eng, args, line, reps=5):
             kname = "conv_ca<c(i) -> a(i+1) fused>"
         elif op.kind == _lib.AF_OP_CONV_BC:
             kname = "conv133g<b + c fused>"
+        elif op.kind == _lib.AF_OP_BLOCK_ABC:
+            kname = "block_abc<a + b + c of a narrow block>"
         elif op.kind in (_lib.AF_OP_STEM, _lib.AF_OP_STEM_POOL, _lib.AF_OP_STEM3_POOL, _lib.AF_OP_TSTEM):
             kname = {_lib.AF_OP_STEM: "stem_kernel", _lib.AF_OP_STEM_POOL: "stem_pool_kernel", _lib.AF_OP_STEM3_POOL: "stem3_pool_kernel",
                      _lib.AF_OP_TSTEM: "tstem_kernel"}[op.kind]

@@ -9,8 +9,8 @@ LIB_PATH = os.environ.get("AF_HIP_LIB") or os.path.join(HERE, "libafhip.so")   #
 AF_F32, AF_BF16, AF_F16 = 0, 1, 2
 (AF_OP_STEM, AF_OP_CONV, AF_OP_MAXPOOL, AF_OP_HEAD, AF_OP_PACK_F32, AF_OP_PACK_U8, AF_OP_CONV_DUAL, AF_OP_STEM_POOL, AF_OP_AVGPOOL,
  AF_OP_LINEAR, AF_OP_TSTEM, AF_OP_TOKENS, AF_OP_LAYERNORM, AF_OP_ATTENTION, AF_OP_GELU, AF_OP_CONV_BC, AF_OP_PACK3_F32,
- AF_OP_PACK3_U8, AF_OP_STEM3_POOL, AF_OP_CONV_CA) = range(20)
-AF_ABI_VERSION = 2
+ AF_OP_PACK3_U8, AF_OP_STEM3_POOL, AF_OP_CONV_CA, AF_OP_BLOCK_ABC) = range(21)
+AF_ABI_VERSION = 3
 STEM_PAD_T, STEM_PAD_H, STEM_PAD_W_LEFT, STEM_PAD_W_TOTAL, STEM_CPAD = 2, 3, 3, 8, 4
 
 DTYPE_CODES = {"f32": AF_F32, "bf16": AF_BF16, "f16": AF_F16}
@@ -49,6 +49,7 @@ class Op(C.Structure):
         ("scores", C.c_void_p),
         ("scale2", C.c_void_p), ("shift2", C.c_void_p),
         ("conv3", ConvDesc), ("in3", C.c_void_p), ("weight3", C.c_void_p),
+        ("scale3", C.c_void_p), ("shift3", C.c_void_p),
     ]
 
 
@@ -88,6 +89,9 @@ ABI = {
     "af_conv_bc_fusable": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvDesc)]),
     "af_conv3d_bc_bn_act": (C.c_int, [C.POINTER(ConvDesc)] + [C.c_void_p] * 4 + [C.POINTER(ConvDesc)] + [C.c_void_p] * 5
                             + [C.c_int, C.c_void_p]),
+    "af_block_abc_fusable": (C.c_int, [C.POINTER(ConvDesc)] * 3),
+    "af_block_abc_bn_act": (C.c_int, ([C.POINTER(ConvDesc)] + [C.c_void_p] * 4) + ([C.POINTER(ConvDesc)] + [C.c_void_p] * 3) * 2
+                            + [C.c_void_p, C.c_int, C.c_void_p]),
     "af_conv_variant": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvDesc)]),
     "af_conv_variant_name": (C.c_char_p, [C.c_int]),
     "af_maxpool3d": (C.c_int, [C.POINTER(PoolDesc), C.c_void_p, C.c_void_p, C.c_void_p]),

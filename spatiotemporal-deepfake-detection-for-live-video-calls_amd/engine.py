@@ -20,10 +20,11 @@ _TORCH_DTYPE = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float
 
 # op tags (echoed by the timed runner; used by bench.py to attribute device time to kernel classes)
 TAG_PACK, TAG_STEM, TAG_POOL, TAG_HEAD = 0, 1, 2, 3
-TAG_CONV_1x1x1, TAG_CONV_Tx1x1, TAG_CONV_1x3x3, TAG_CONV_OTHER, TAG_CONV_BC, TAG_CONV_CA = 10, 11, 12, 13, 14, 15
+TAG_CONV_1x1x1, TAG_CONV_Tx1x1, TAG_CONV_1x3x3, TAG_CONV_OTHER, TAG_CONV_BC, TAG_CONV_CA, TAG_BLOCK_ABC = 10, 11, 12, 13, 14, 15, 16
 TAG_NAMES = {TAG_PACK: "input_pack", TAG_STEM: "stem_5x7x7", TAG_POOL: "maxpool", TAG_HEAD: "head",
              TAG_CONV_1x1x1: "conv_1x1x1", TAG_CONV_Tx1x1: "conv_3x1x1", TAG_CONV_1x3x3: "conv_1x3x3",
-             TAG_CONV_OTHER: "conv_other", TAG_CONV_BC: "conv_1x3x3+1x1x1_fused", TAG_CONV_CA: "conv_1x1x1+3x1x1_fused"}
+             TAG_CONV_OTHER: "conv_other", TAG_CONV_BC: "conv_1x3x3+1x1x1_fused", TAG_CONV_CA: "conv_1x1x1+3x1x1_fused",
+             TAG_BLOCK_ABC: "bottleneck_block_fused"}
 TAG_NAMES[TAG_STEM] = "stem"
 
 
@@ -199,6 +200,22 @@ class _Plan:
             _fill_conv_desc(d3, self.batch, self.code, branch1, d_in, dc, True)
         return bool(lib.af_conv_ca_fusable(C.byref(d1), C.byref(d3) if branch1 is not None else None, C.byref(d2)))
 
+    def abc_fusable(self, blk, d) -> bool:
+        """does the library run this whole identity-shortcut block (a, b, c + residual + ReLU) as one launch
+        (af_block_abc_bn_act: the narrow blocks of SlowFast's Fast pathway)?  AF_FUSE_ABC=0 switches it off (A/B runs)."""
+        if self.code is None or os.environ.get("AF_FUSE_ABC", "1") != "1" or blk.branch1 is not None:
+            return False
+        if any(cv.pool_after_bn is not None for cv in (blk.a, blk.b, blk.c)):
+            return False
+        da = blk.a.out_dims(*d)
+        db = blk.b.out_dims(*da)
+        dc = blk.c.out_dims(*db)
+        d1, d2, d3 = _lib.ConvDesc(), _lib.ConvDesc(), _lib.ConvDesc()
+        _fill_conv_desc(d1, self.batch, self.code, blk.a, d, da, True)
+        _fill_conv_desc(d2, self.batch, self.code, blk.b, da, db, True)
+        _fill_conv_desc(d3, self.batch, self.code, blk.c, db, dc, True)
+        return bool(lib.af_block_abc_fusable(C.byref(d1), C.byref(d2), C.byref(d3)))
+
     def stage(self, stage, d, cur, nxt, a_buf, b_buf, last_ld=None, tpool_last=False):
         """One pathway's ResStage.  ``last_ld``: row stride of the stage's final output (room for the lateral's
         channels).  Returns (dims, channels, buffer holding the output, the other trunk buffer)."""
@@ -207,6 +224,14 @@ class _Plan:
         a_done = False                       # this block's a conv was run by the previous block's fused c -> a launch
         for bi, blk in enumerate(stage.blocks):
             last = bi == nblk - 1
+            if not a_done and not (tpool_last and last) and self.abc_fusable(blk, d):
+                # the whole block in one launch (narrow pathway): trunk in, trunk out, a and b stay on the CU
+                ld = last_ld if (last and last_ld) else blk.c.cout
+                self.add(kind="abc", cv=blk.a, cv2=blk.b, cv3=blk.c, din=d, dout=d, src=cur, dst=nxt, ld=ld)
+                self.need(nxt, d, ld)
+                cur, nxt = nxt, cur
+                c = blk.c.cout
+                continue
             da = blk.a.out_dims(*d)
             if not a_done:
                 self.add(kind="conv", cv=blk.a, din=d, dout=da, src=cur, dst=a_buf)
@@ -501,6 +526,21 @@ class Engine:
                 op.out_ld = cvc.cout
                 self.op_names.append(cvc.conv + ("+branch1" if e.get("cv3") is not None else "") + "->" + cva.conv.split("resnet.")[-1])
                 self.op_macs.append(batch * macs)
+            elif kind == "abc":
+                cva, cvb, cvc = e["cv"], e["cv2"], e["cv3"]
+                op.kind, op.tag = _lib.AF_OP_BLOCK_ABC, TAG_BLOCK_ABC
+                fill_conv(op.conv, cva, e["din"], e["din"], True)
+                fill_conv(op.conv2, cvb, e["din"], e["din"], True)
+                fill_conv(op.conv3, cvc, e["din"], e["din"], True)       # final_bn: takes the block's add + ReLU
+                op.weight, op.scale, op.shift = (weights.w[cva.conv].data_ptr(), weights.scale[cva.conv].data_ptr(),
+                                                 weights.shift[cva.conv].data_ptr())
+                op.weight2, op.scale2, op.shift2 = (weights.w[cvb.conv].data_ptr(), weights.scale[cvb.conv].data_ptr(),
+                                                    weights.shift[cvb.conv].data_ptr())
+                op.weight3, op.scale3, op.shift3 = (weights.w[cvc.conv].data_ptr(), weights.scale[cvc.conv].data_ptr(),
+                                                    weights.shift[cvc.conv].data_ptr())
+                op.out_ld = e.get("ld", cvc.cout)
+                self.op_names.append(cva.conv.rsplit(".", 1)[0] + ".a+b+c")
+                self.op_macs.append(batch * (cva.macs(*e["din"]) + cvb.macs(*e["din"]) + cvc.macs(*e["din"])))
             elif kind == "bc":
                 cvb, cvc = e["cv"], e["cv2"]
                 op.kind, op.tag = _lib.AF_OP_CONV_BC, TAG_CONV_BC
@@ -735,6 +775,8 @@ class Engine:
             shape = (op.conv.n, op.conv.to, (op.conv.ho - 1) // 2 + 1, (op.conv.wo - 1) // 2 + 1, op.conv.cout)
         elif op.kind == _lib.AF_OP_CONV_BC:
             shape = (op.conv2.n, op.conv2.to, op.conv2.ho, op.conv2.wo, op.out_ld or op.conv2.cout)
+        elif op.kind == _lib.AF_OP_BLOCK_ABC:
+            shape = (op.conv3.n, op.conv3.to, op.conv3.ho, op.conv3.wo, op.out_ld or op.conv3.cout)
         elif op.kind == _lib.AF_OP_CONV_CA:        # the trunk
             shape = (op.conv.n, op.conv.to, op.conv.ho, op.conv.wo, op.conv.cout)
         elif op.kind in (_lib.AF_OP_STEM, _lib.AF_OP_CONV, _lib.AF_OP_CONV_DUAL, _lib.AF_OP_TSTEM):

@@ -110,6 +110,33 @@ def conv_bc(x_ndhwc, wb_oidhw, bn_b, wc_oidhw, bn_c, residual, dtype):
     return out
 
 
+def block_abc(x_ndhwc, wa_oidhw, bn_a, wb_oidhw, bn_b, wc_oidhw, bn_c, dtype, out_ld=0):
+    """relu(x + bn_c(c(relu(bn_b(b(relu(bn_a(a(x)))))))))  as one af_block_abc_bn_act launch (a: kT x 1 x 1, b: 1x3x3, c: 1x1x1);
+    None if the library does not fuse this triple (af_block_abc_fusable)."""
+    L = lib()
+    code = L.DTYPE_CODES[dtype]
+    n, t, h, w, ctrunk = x_ndhwc.shape
+    inner, kta = wa_oidhw.shape[0], wa_oidhw.shape[2]
+    da, db, dc = L.ConvDesc(), L.ConvDesc(), L.ConvDesc()
+    for d, (ci, co, k, p) in zip((da, db, dc), ((ctrunk, inner, (kta, 1, 1), (kta // 2, 0, 0)), (inner, inner, (1, 3, 3), (0, 1, 1)),
+                                                (inner, wc_oidhw.shape[0], (1, 1, 1), (0, 0, 0)))):
+        d.n, d.t, d.h, d.w, d.cin, d.cout = n, t, h, w, ci, co
+        d.kt, d.kh, d.kw = k
+        d.st = d.sh = d.sw = 1
+        d.pt, d.ph, d.pw = p
+        d.to, d.ho, d.wo, d.relu, d.dtype = t, h, w, 1, code
+    if not L.lib.af_block_abc_fusable(C.byref(da), C.byref(db), C.byref(dc)):
+        return None
+    pa, pb, pc = _pack_plain(wa_oidhw, dtype), _pack_plain(wb_oidhw, dtype), _pack_plain(wc_oidhw, dtype)
+    ld = out_ld or wc_oidhw.shape[0]
+    out = torch.full((n, t, h, w, ld), 7.0, dtype=TORCH_DT[dtype], device="cuda")
+    L.check(L.lib.af_block_abc_bn_act(C.byref(da), _p(x_ndhwc), _p(pa), _p(bn_a[0]), _p(bn_a[1]), C.byref(db), _p(pb), _p(bn_b[0]),
+                                      _p(bn_b[1]), C.byref(dc), _p(pc), _p(bn_c[0]), _p(bn_c[1]), _p(out), out_ld, _stream()),
+            "block_abc_bn_act")
+    torch.cuda.current_stream().synchronize()
+    return out
+
+
 def conv_ca(b_ndhwc, wc_oidhw, bn_c, res_ndhwc, wa_oidhw, bn_a, dtype, x0_ndhwc=None, w1_oidhw=None, bn_1=None):
     """x = relu(bn_c(conv1x1x1(b)) + res), a_out = relu(bn_a(conv3x1x1(x))) as one af_conv3d_ca_bn_act launch -> (x, a_out);
     with x0 / w1 / bn_1 (a projection block) x = relu(bn_c(c(b)) + bn_1(conv1x1x1_1(x0))) and res must be None.

@@ -506,6 +506,49 @@ def test_fused_b_c_vs_oracle(name, cin, cmid, cout, dims, use_res, dtype):
 
 
 @pytest.mark.parametrize("dtype", ["f16", "bf16"])
+@pytest.mark.parametrize("name,inner,kta,dims,out_ld", [
+    ("fast_s2_like", 8, 3, (2, 12, 56, 56), 0),          # 14 x 14 patches, 16 per frame, 2 time segments of 6 frames... per clip
+    ("fast_s2_ragged", 8, 3, (1, 9, 37, 45), 0),         # ragged patch rows / columns (37 = 2 x 14 + 9, 45 = 3 x 14 + 3), odd T
+    ("fast_s3_like", 16, 3, (2, 16, 28, 28), 0),         # inner 16: 7-row patches, two K-blocks per tap in a
+    ("fast_s3_kt1_wide_rows", 16, 1, (1, 8, 20, 30), 80),   # a without temporal taps; output rows wider than the trunk (concat buffer)
+    ("one_frame", 8, 3, (1, 1, 14, 14), 0),              # T = 1: both temporal taps fall outside the clip
+    ("fast_s4_like", 32, 3, (2, 16, 14, 14), 0),         # inner 32: two channel tiles in a / b, 3-row patches, 4 K-blocks per tap
+    ("fast_s4_ragged_kt1", 32, 1, (1, 5, 10, 17), 0),
+])
+def test_fused_block_a_b_c_vs_oracle(name, inner, kta, dims, out_ld, dtype, monkeypatch):
+    """af_block_abc_bn_act: a whole identity-shortcut bottleneck of SlowFast's Fast pathway (kT x 1 x 1 -> 1x3x3 -> 1x1x1, + x,
+    ReLU) in one launch against three oracle conv_bn_act calls in fp64; a and b are rounded to the storage type on both sides
+    (they cross LDS in it).  Columns beyond the block's channels of a wider output row must stay untouched."""
+    if inner == 32:
+        monkeypatch.setenv("AF_ABC_INNER32", "1")                # correct but not faster than three launches: off by default
+    seed = 6000 + sum(map(ord, name))
+    C4 = 4 * inner
+    lay = [("a.weight", (inner, C4, kta, 1, 1), "float32"), ("b.weight", (inner, inner, 1, 3, 3), "float32"),
+           ("c.weight", (C4, inner, 1, 1, 1), "float32")]
+    for p_, ch in (("a_bn", inner), ("b_bn", inner), ("c_bn", C4)):
+        lay += [(p_ + s_, (ch,), "float32") for s_ in (".weight", ".bias", ".running_mean", ".running_var")]
+    sd = synth.fill_layout(lay, seed)
+    tdt = hh.TORCH_DT[dtype]
+    x = synth.synthetic_tensor((dims[0], C4) + dims[1:], seed).to(tdt).float()
+    for k in ("a.weight", "b.weight", "c.weight"):
+        sd[k] = sd[k].to(tdt).float()
+    sd64 = {k: v.double() for k, v in sd.items()}
+    ya = oracle.conv_bn_act(x.double(), sd64["a.weight"], sd64, "a_bn", (1, 1, 1), (kta // 2, 0, 0), True).to(tdt).double()
+    yb = oracle.conv_bn_act(ya, sd64["b.weight"], sd64, "b_bn", (1, 1, 1), (0, 1, 1), True).to(tdt).double()
+    want = F.relu(oracle.conv_bn_act(yb, sd64["c.weight"], sd64, "c_bn", (1, 1, 1), (0, 0, 0), False) + x.double())
+    got = hh.block_abc(hh.to_ndhwc(x, dtype), sd["a.weight"], hh.fold_bn(sd, "a_bn"), sd["b.weight"], hh.fold_bn(sd, "b_bn"),
+                       sd["c.weight"], hh.fold_bn(sd, "c_bn"), dtype, out_ld=out_ld)
+    assert got is not None, "the library should fuse this block"
+    if out_ld:
+        assert torch.all(got[..., C4:] == 7.0), "columns beyond the block's channels were written"
+        got = got[..., :C4]
+    got = hh.to_ncdhw(got.contiguous()).double()
+    tol = {"f16": 3e-3, "bf16": 2.4e-2}[dtype]                   # two intermediates on rounding boundaries may round the other way
+    err = (got - want).abs().max().item()
+    assert err <= tol * (want.abs().max().item() + 1e-9), "%s[%s] err %.3e" % (name, dtype, err)
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
 @pytest.mark.parametrize("name,ctrunk,dims", [
     ("s2_like_T32", 256, (2, 32, 64, 66)),        # T = 32: 8 pixels per tile, 4 K slabs; 1 056 tiles >= 4 per CU
     ("T16_two_slabs", 128, (3, 16, 76, 76)),      # T = 16: 16 pixels per tile, 2 K slabs, 1 083 tiles
