@@ -121,7 +121,8 @@ def roofline_report(eng, args, line, reps=5):
         elif op.kind == _lib.AF_OP_BLOCK_ABC:            # trunk in + trunk out + the three weights; a and b stay on chip
             ca, cb, cc_ = op.conv, op.conv2, op.conv3
             pos = ca.n * ca.t * ca.h * ca.w
-            eng_bytes[i] = es * (pos * (ca.cin + cc_.cout) + ca.cout * ca.cin * ca.kt + cb.cout * cb.cin * 9 + cc_.cout * cc_.cin)
+            eng_bytes[i] = es * (pos * (ca.cin + cc_.cout) + ca.cout * ca.cin * ca.kt + cb.cout * cb.cin * 9 + cc_.cout * cc_.cin
+                                 + (op.conv4.cout * op.conv4.cin if op.weight4 else 0))
         elif op.kind == _lib.AF_OP_CONV_BC:              # b input + c output + residual + both weights; the b output stays on chip
             cb, cc_ = op.conv, op.conv2
             pos = cb.n * cb.to * cb.ho * cb.wo

@@ -175,17 +175,20 @@ int af_conv3d_dual_bn_act(const af_conv_desc* d, const void* in, const void* w_p
                           const af_conv_desc* d2, const void* in2, const void* w2_packed,
                           const float* scale, const float* shift, void* out, int out_ld, void* stream);
 
-/* A whole identity-shortcut bottleneck block of a NARROW pathway as ONE launch (ABI 3):
- *     out = relu( x + bn_c(conv_c( relu(bn_b(conv_b( relu(bn_a(conv_a(x))) ))) )) )
+/* A whole bottleneck block of a NARROW pathway as ONE launch (ABI 3):
+ *     out = relu( shortcut(x) + bn_c(conv_c( relu(bn_b(conv_b( relu(bn_a(conv_a(x))) ))) )) )
  * = ResBlock.forward over BottleneckTransform (resnet_helper.py:255-326, 411-444) as SlowFast's Fast pathway instantiates it
- * (video_model_builder.py:146-387: dim_inner 8 / 16, trunk 32 / 64 channels).  da: kT x 1 x 1 (kT = 1 or 3) C -> C/4, db: 1x3x3
- * C/4 -> C/4, dc: 1x1x1 C/4 -> C, all stride 1, 16-bit, C/4 = 8 or 16; the a and b tensors never leave the CU.  `x` is both the
- * input and the residual and must not alias `out`.  af_block_abc_fusable() says whether a triple takes this path. */
-int af_block_abc_fusable(const af_conv_desc* da, const af_conv_desc* db, const af_conv_desc* dc);
+ * (video_model_builder.py:146-387: dim_inner 8 / 16, trunk 32 / 64 channels).  da: kT x 1 x 1 (kT = 1 or 3) -> C/4, db: 1x3x3
+ * C/4 -> C/4, dc: 1x1x1 C/4 -> C, all stride 1, 16-bit, C/4 = 8 or 16; the a and b tensors never leave the CU.
+ * d1 == NULL: identity shortcut (x has C channels and is also the residual).  d1 != NULL (block 0 of the Fast pathway's s2:
+ * 8 -> 32 channels): shortcut = bn_1(conv_1x1x1(x)), computed like af_conv3d_dual_bn_act does - wc_packed and w1_packed carry
+ * their BN scale (af_pack_conv_weight_scaled), scale_c is all ones and shift_c = shift_c + shift_1.  `x` must not alias `out`.
+ * af_block_abc_fusable() says whether a block takes this path. */
+int af_block_abc_fusable(const af_conv_desc* da, const af_conv_desc* db, const af_conv_desc* dc, const af_conv_desc* d1);
 int af_block_abc_bn_act(const af_conv_desc* da, const void* x, const void* wa_packed, const float* scale_a, const float* shift_a,
                         const af_conv_desc* db, const void* wb_packed, const float* scale_b, const float* shift_b,
                         const af_conv_desc* dc, const void* wc_packed, const float* scale_c, const float* shift_c,
-                        void* out, int out_ld, void* stream);
+                        const af_conv_desc* d1, const void* w1_packed, void* out, int out_ld, void* stream);
 
 /* The 1x3x3 `b` conv (+BN+ReLU) and the 1x1x1 `c` conv (+BN) of a bottleneck + the ResBlock's residual add + ReLU
  * (resnet_helper.py:283-325, 438-444) as ONE launch: relu( bn_c(conv_c( relu(bn_b(conv_b(in))) )) + residual ).  The b
@@ -339,9 +342,9 @@ enum af_op_kind { AF_OP_STEM = 0, AF_OP_CONV = 1, AF_OP_MAXPOOL = 2, AF_OP_HEAD 
                   /* c of a block + a of the next in one launch: conv / weight / scale / shift / residual / out = the c conv and
                      the trunk, conv2 / weight2 / scale2 / shift2 / aux = the a conv and its output (af_conv3d_ca_bn_act) */
                   AF_OP_CONV_CA = 19,
-                  /* a narrow identity-shortcut block in one launch: conv / weight / scale / shift = a, conv2 / weight2 / scale2 /
-                     shift2 = b, conv3 / weight3 / scale3 / shift3 = c, in = the trunk (input and residual), out, out_ld
-                     (af_block_abc_bn_act) */
+                  /* a narrow bottleneck block in one launch: conv / weight / scale / shift = a, conv2 / weight2 / scale2 / shift2 = b,
+                     conv3 / weight3 / scale3 / shift3 = c, in = the trunk (input and residual), out, out_ld; projection form:
+                     pool is unused, in2 == in and (conv4, weight4) = the shortcut conv (af_block_abc_bn_act) */
                   AF_OP_BLOCK_ABC = 20 };
 
 typedef struct af_op {
@@ -377,9 +380,11 @@ typedef struct af_op {
     af_conv_desc conv3;
     const void* in3;
     const void* weight3;
-    /* BLOCK_ABC: BatchNorm of the third conv (ABI 3) */
+    /* BLOCK_ABC: BatchNorm of the third conv; the projection shortcut of its block-0 form (weight4 == NULL: identity) (ABI 3) */
     const float* scale3;
     const float* shift3;
+    af_conv_desc conv4;
+    const void* weight4;
 } af_op;
 
 /* Enqueue ops[0..n) in order on `stream` (AltFreezing: ResNet.forward, video_model_builder.py:561-578). */

@@ -50,6 +50,7 @@ class Op(C.Structure):
         ("scale2", C.c_void_p), ("shift2", C.c_void_p),
         ("conv3", ConvDesc), ("in3", C.c_void_p), ("weight3", C.c_void_p),
         ("scale3", C.c_void_p), ("shift3", C.c_void_p),
+        ("conv4", ConvDesc), ("weight4", C.c_void_p),
     ]
 
 
@@ -89,9 +90,9 @@ ABI = {
     "af_conv_bc_fusable": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvDesc)]),
     "af_conv3d_bc_bn_act": (C.c_int, [C.POINTER(ConvDesc)] + [C.c_void_p] * 4 + [C.POINTER(ConvDesc)] + [C.c_void_p] * 5
                             + [C.c_int, C.c_void_p]),
-    "af_block_abc_fusable": (C.c_int, [C.POINTER(ConvDesc)] * 3),
+    "af_block_abc_fusable": (C.c_int, [C.POINTER(ConvDesc)] * 4),
     "af_block_abc_bn_act": (C.c_int, ([C.POINTER(ConvDesc)] + [C.c_void_p] * 4) + ([C.POINTER(ConvDesc)] + [C.c_void_p] * 3) * 2
-                            + [C.c_void_p, C.c_int, C.c_void_p]),
+                            + [C.POINTER(ConvDesc), C.c_void_p] + [C.c_void_p, C.c_int, C.c_void_p]),
     "af_conv_variant": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvDesc)]),
     "af_conv_variant_name": (C.c_char_p, [C.c_int]),
     "af_maxpool3d": (C.c_int, [C.POINTER(PoolDesc), C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -212,22 +212,15 @@ class FasterCropAlignXRay:
         k = self._ring.acquire(total, dev)
         hv = self._ring.host[k].numpy()
         pairs = [(hv[o:o + im.size], im) for im, o in zip(images, offs)]
-        d, h = self._ring.dev[k], self._ring.host[k]
-        # in a few chunks of frames: while chunk i crosses PCIe, chunk i + 1 is being copied into the pinned slot
-        nchunks = 4 if (len(pairs) >= 8 and total >= (4 << 20)) else 1
-        per = (len(pairs) + nchunks - 1) // nchunks
-        for c in range(nchunks):
-            part = pairs[c * per:(c + 1) * per]
-            if not part:
-                break
-            nt = min(_COPY_THREADS, len(part))
-            if nt > 1 and total >= (1 << 20):
-                list(_pool().map(_copy_group, [part[i::nt] for i in range(nt)]))
-            else:
-                _copy_group(part)
-            lo = offs[c * per]
-            hi = offs[(c + 1) * per] if (c + 1) * per < len(offs) else total
-            d[lo:hi].copy_(h[lo:hi], non_blocking=True)
+        # (staging in four chunks, each crossing PCIe while the next is copied, was tried: the extra pool round trips and small
+        #  copies cost more than the overlap gained - host-inclusive 1 780 -> 860 clips/s)
+        nt = min(_COPY_THREADS, len(pairs))
+        if nt > 1 and total >= (1 << 20):
+            list(_pool().map(_copy_group, [pairs[i::nt] for i in range(nt)]))
+        else:
+            _copy_group(pairs)
+        d = self._ring.dev[k]
+        d[:total].copy_(self._ring.host[k][:total], non_blocking=True)
         return d, offs, k
 
     @staticmethod

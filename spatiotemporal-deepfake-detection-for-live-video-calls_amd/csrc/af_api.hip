@@ -46,7 +46,8 @@ static int run_one(const af_op& op, hipStream_t s) {
                                        op.residual, op.out, &op.conv2, op.weight2, op.scale2, op.shift2, op.aux, s);
         case AF_OP_BLOCK_ABC:   /* in = the trunk: input and residual */
             return af_block_abc_bn_act(&op.conv, op.in, op.weight, op.scale, op.shift, &op.conv2, op.weight2, op.scale2, op.shift2,
-                                       &op.conv3, op.weight3, op.scale3, op.shift3, op.out, op.out_ld, s);
+                                       &op.conv3, op.weight3, op.scale3, op.shift3, op.weight4 ? &op.conv4 : nullptr, op.weight4,
+                                       op.out, op.out_ld, s);
         case AF_OP_MAXPOOL:
             return af_maxpool3d(&op.pool, op.in, op.out, s);
         case AF_OP_HEAD:

@@ -18,6 +18,9 @@
 //     waves 4-7 only, while all LDS-DMA is issued by waves 0-3: the top-of-step vmcnt(0) that makes the next frame visible then
 //     waits for loads only (with one wave doing both it also waited ~1.5 us per frame for the store acknowledgements).
 // HBM traffic = the trunk in (x 1.3 - 1.5 for the halo) and out; the matrix work is a few dozen MFMAs per wave and frame.
+// PROJ form (block 0 of the Fast pathway's s2: 8 -> 32 channels, stride 1): the input has CIN channels instead of C, the shortcut
+// is the 1x1x1 projection `branch1` (resnet_helper.py:411-436) accumulated into c's tile like af_conv3d_dual_bn_act does - both
+// weight sets carry their BN scale (folded in fp32 by the caller), shift = shift_c + shift_1 - and no residual is added.
 #include "af_common.h"
 #include <stdlib.h>
 
@@ -26,6 +29,7 @@ namespace af {
 struct ABCArgs {
     const char* x;            // [N][T][H][W][C]
     const char *wa, *wb, *wc; // packed [64][taps][64] (af_pack_conv_weight)
+    const char* w1;           // PROJ: the projection shortcut's packed weight (BN scale folded), else null
     const float *sa, *ha, *sb, *hb, *sc, *hc;   // BN scale / shift of a, b, c
     char* y;                  // [N][T][H][W][out_ld]
     int T, H, W, kta;
@@ -36,31 +40,37 @@ struct ABCArgs {
 
 constexpr int kAbcRing = 4;
 
-template <int INNER> struct AbcDims {
-    static constexpr int C = 4 * INNER;                // trunk channels
-    static constexpr int PB = C * 2, AB = INNER * 2;   // bytes per trunk / inner pixel
-    static constexpr int KBA = C / 32;                 // K-blocks per temporal tap of a
+template <int INNER, int CIN> struct AbcDims {
+    static constexpr int C = 4 * INNER;                // trunk channels out (= CIN for an identity-shortcut block)
+    static constexpr bool PROJ = CIN != C;
+    static constexpr int PB = C * 2, AB = INNER * 2;   // bytes per output / inner pixel
+    static constexpr int PBI = CIN * 2;                // bytes per input pixel
+    static constexpr int SPTA = CIN / 8;               // 16-byte K-slots per temporal tap of a (and K-slots of the projection)
     static constexpr int SPT = INNER / 8;              // 16-byte K-slots per tap of b (and K-slots of c)
     static constexpr int NBB = (9 * SPT + 3) / 4;      // K-blocks of b
+    static constexpr int NB1 = PROJ ? (SPTA + 3) / 4 : 0;   // K-blocks of the projection shortcut
     static constexpr int NTA = (INNER + 15) / 16;      // channel tiles of a and b
     static constexpr int NTC = C / 16;                 // channel tiles of c
-    static constexpr int CPP = PB / 16;                // 16-byte chunks per trunk pixel
-    static constexpr int PPR = CPP / 4;                // DMA pieces per haloed row (16 pixels)
+    static constexpr int CPP = PB / 16;                // 16-byte chunks per output pixel
+    static constexpr int CPPI = PBI / 16;              // ... per input pixel
 };
 
-static inline int abc_lds_bytes(int inner, int ph, int kta) {
-    const int C = 4 * inner, PB = C * 2, AB = inner * 2, rows = ph + 2;
+static inline int abc_lds_bytes(int inner, int cin, int ph, int kta) {
+    const int C = 4 * inner, PB = C * 2, PBI = cin * 2, AB = inner * 2, rows = ph + 2;
     const int nta = (inner + 15) / 16;
-    const int nfrag = (kta * (C / 32) + (9 * (inner / 8) + 3) / 4) * nta + C / 16;
-    return kAbcRing * rows * 16 * PB + (rows * 16 + 34) * AB + rows * 16 * AB + ph * 16 * PB + nfrag * 1024 + (2 * 32 + 2 * 32 + 2 * C) * 4;
+    const int nfrag = ((kta * (cin / 8) + 3) / 4 + (9 * (inner / 8) + 3) / 4) * nta + C / 16 * (1 + (cin != C ? (cin / 8 + 3) / 4 : 0));
+    return kAbcRing * rows * 16 * PBI + (rows * 16 + 34) * AB + rows * 16 * AB + ph * 16 * PB + nfrag * 1024 + (2 * 32 + 2 * 32 + 2 * C) * 4;
 }
 
-template <int DT, int INNER>
+template <int DT, int INNER, int CIN>
 __global__ __launch_bounds__(512, 2) void block_abc_kernel(const ABCArgs a) {
     typedef Elem<DT> E;
-    typedef AbcDims<INNER> D;
+    typedef AbcDims<INNER, CIN> D;
     static_assert(E::EPC == 8 && (INNER == 8 || INNER == 16 || INNER == 32), "16-bit operands, inner width 8, 16 or 32");
-    constexpr int C = D::C, PB = D::PB, AB = D::AB, KBA = D::KBA, SPT = D::SPT, NBB = D::NBB, NTA = D::NTA, NTC = D::NTC, CPP = D::CPP, PPR = D::PPR;
+    constexpr int C = D::C, PB = D::PB, PBI = D::PBI, AB = D::AB, SPTA = D::SPTA, SPT = D::SPT, NBB = D::NBB, NB1 = D::NB1, NTA = D::NTA, NTC = D::NTC,
+                  CPP = D::CPP, CPPI = D::CPPI;
+    constexpr bool PROJ = D::PROJ;
+    constexpr int CINP = CIN > 64 ? (CIN + 63) / 64 * 64 : 64;       // packed row pitch per tap of a / the projection
 
     extern __shared__ uint4 smem[];
     char* sm = reinterpret_cast<char*>(smem);
@@ -69,28 +79,33 @@ __global__ __launch_bounds__(512, 2) void block_abc_kernel(const ABCArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int frow = lane & 15, fg = lane >> 4;
     const int ROWS = a.PH + 2;
-    const int slot_bytes = ROWS * 16 * PB;
+    const int slot_bytes = ROWS * 16 * PBI;
     char* abuf = sm + kAbcRing * slot_bytes;                       // a(t): haloed pixel p at entry 17 + p (guards: taps of dropped columns)
     char* bbuf = abuf + (ROWS * 16 + 34) * AB;                     // b(t)
     char* ybuf = bbuf + ROWS * 16 * AB;                            // y(t): rows 1 .. PH of the haloed patch
-    uint4* wfr = reinterpret_cast<uint4*>(ybuf + a.PH * 16 * PB);  // A fragments: a (kta * KBA), b (NBB), c (NTC); 64 lanes x 16 B each
-    const int nfa = a.kta * KBA * NTA, nfb = NBB * NTA;            // fragment index: (K-block, channel tile)
-    float* bn = reinterpret_cast<float*>(wfr + (nfa + nfb + NTC) * 64);   // a: scale[32] shift[32]; b: the same; c: scale[C] shift[C]
+    uint4* wfr = reinterpret_cast<uint4*>(ybuf + a.PH * 16 * PB);  // A fragments: a, b, c (, projection); 64 lanes x 16 B each
+    // K of a as 16-byte slots: slot s = (tap dt = s / SPTA, 8-channel part s % SPTA) of kta * SPTA; four slots per K-block
+    const int nsa = a.kta * SPTA, nba = (nsa + 3) >> 2;
+    const int nfa = nba * NTA, nfb = NBB * NTA, nf1 = NB1 * NTC;   // fragment index: (K-block, channel tile)
+    float* bn = reinterpret_cast<float*>(wfr + (nfa + nfb + NTC + nf1) * 64);   // a: scale[32] shift[32]; b: the same; c: scale[C] shift[C]
 
     // ---- weights -> LDS in fragment order (lane = (output channel row frow, K-group fg)); BN parameters
-    for (int idx = tid; idx < (nfa + nfb + NTC) * 64; idx += 512) {
+    for (int idx = tid; idx < (nfa + nfb + NTC + nf1) * 64; idx += 512) {
         const int f = idx >> 6, l = idx & 63, g = l >> 4;
         uint4 v = uint4{0u, 0u, 0u, 0u};
         if (f < nfa) {
-            const int blk = f / NTA, o = (f - blk * NTA) * 16 + (l & 15), dt = blk / KBA, kb = blk - dt * KBA;
-            v = *reinterpret_cast<const uint4*>(a.wa + (((long long)o * a.kta + dt) * (C > 64 ? C : 64) + kb * 32 + g * 8) * 2);
+            const int blk = f / NTA, o = (f - blk * NTA) * 16 + (l & 15), sl = 4 * blk + g, dt = sl / SPTA, part = sl - dt * SPTA;
+            if (sl < nsa) v = *reinterpret_cast<const uint4*>(a.wa + (((long long)o * a.kta + dt) * CINP + part * 8) * 2);
         } else if (f < nfa + nfb) {
             const int blk = (f - nfa) / NTA, o = ((f - nfa) - blk * NTA) * 16 + (l & 15);
-            const int s = 4 * blk + g, tap = s / SPT, part = s - tap * SPT;
+            const int sl = 4 * blk + g, tap = sl / SPT, part = sl - tap * SPT;
             if (tap < 9) v = *reinterpret_cast<const uint4*>(a.wb + (((long long)o * 9 + tap) * 64 + part * 8) * 2);
-        } else {
+        } else if (f < nfa + nfb + NTC) {
             const int nt = f - nfa - nfb;
             v = *reinterpret_cast<const uint4*>(a.wc + ((long long)(nt * 16 + (l & 15)) * 64 + g * 8) * 2);   // columns >= INNER are zero
+        } else {
+            const int q1 = f - nfa - nfb - NTC, blk = q1 / NTC, nt = q1 - blk * NTC, sl = 4 * blk + g;
+            if (sl < SPTA) v = *reinterpret_cast<const uint4*>(a.w1 + ((long long)(nt * 16 + (l & 15)) * CINP + sl * 8) * 2);
         }
         wfr[idx] = v;
     }
@@ -107,18 +122,20 @@ __global__ __launch_bounds__(512, 2) void block_abc_kernel(const ABCArgs a) {
     const int t0 = ts * a.TS, t1 = (t0 + a.TS < a.T) ? t0 + a.TS : a.T;
     const int h0 = py * a.PH, w0 = px * 14;
     const int pt = a.kta >> 1;
-    const long long frame_bytes = (long long)a.H * a.W * PB;
+    const long long frame_bytes = (long long)a.H * a.W * PBI;
 
-    // trunk patch producer (waves 0-3): piece g = haloed row g / PPR, pixels (g % PPR) * (64 / CPP) + lane / CPP; a producer wave
-    // issues pieces wave, wave + 4, ... (<= 6: ROWS * PPR <= 24)
+    // trunk patch producer (waves 0-3): a frame's haloed patch is ROWS * 16 * CPPI 16-byte chunks, lane-linear in LDS; piece g is
+    // chunks 64 g .. 64 g + 63 (chunk -> pixel chunk / CPPI = (row, column), part chunk % CPPI); a producer wave issues pieces
+    // wave, wave + 4, ... (<= 6 each: <= 24 pieces per frame, host-checked)
     constexpr int MAXP = 6;
+    const int npieces = (ROWS * 16 * CPPI + 63) >> 6;
     unsigned xoff[MAXP];
 #pragma unroll
     for (int i = 0; i < MAXP; ++i) {
-        const int g = wave + 4 * i, r = g / PPR, pxl = (g % PPR) * (64 / CPP) + lane / CPP, part = lane % CPP;
+        const int ck = (wave + 4 * i) * 64 + lane, pix = ck / CPPI, part = ck - pix * CPPI, r = pix >> 4, pxl = pix & 15;
         const int hh = h0 - 1 + r, ww = w0 - 1 + pxl;
-        const bool ok = wave < 4 && g < ROWS * PPR && (unsigned)hh < (unsigned)a.H && (unsigned)ww < (unsigned)a.W;
-        xoff[i] = ok ? (unsigned)(((hh * a.W + ww) * PB) + part * 16) : kOutOfRange;
+        const bool ok = wave < 4 && r < ROWS && (unsigned)hh < (unsigned)a.H && (unsigned)ww < (unsigned)a.W;
+        xoff[i] = ok ? (unsigned)(((hh * a.W + ww) * PBI) + part * 16) : kOutOfRange;
     }
     auto issue_frame = [&](int f) {                                    // uniform f in [0, T); producer waves only
         if (wave >= 4) return;
@@ -126,7 +143,7 @@ __global__ __launch_bounds__(512, 2) void block_abc_kernel(const ABCArgs a) {
         const unsigned base = lds0 + ((f + kAbcRing) & (kAbcRing - 1)) * slot_bytes;
 #pragma unroll
         for (int i = 0; i < MAXP; ++i)
-            if (wave + 4 * i < ROWS * PPR) blds16(xoff[i], desc, 0, __builtin_amdgcn_readfirstlane(base + (wave + 4 * i) * 1024));
+            if (wave + 4 * i < npieces) blds16(xoff[i], desc, 0, __builtin_amdgcn_readfirstlane(base + (wave + 4 * i) * 1024));
     };
     // y(t) leaves as whole pixels, 16 bytes per lane: patch row rr, pixel pxl (haloed column pxl + 1); store waves 4-7 only
     auto store_frame = [&](int t) {
@@ -150,50 +167,77 @@ __global__ __launch_bounds__(512, 2) void block_abc_kernel(const ABCArgs a) {
         if (t + 2 <= f_hi) issue_frame(t + 2);                         // its slot held frame t - 2: dead since a(t - 1)
         if (t > t0) store_frame(t - 1);                                // under this frame's a phase
 
+        // Every phase hands a wave its tiles in PAIRS with two independent accumulators: a tile is a dependent chain (LDS read ->
+        // MFMA -> ... -> BN -> LDS write, ~350 cycles of latency for a few dozen of issue), two interleaved chains cost little
+        // more than one (the second tile of an odd count is clamped onto the first and not written back).
         // ---- a(t): kT x 1 x 1 over the haloed patch, one row of 16 pixels per MFMA tile
-        for (int it = wave; it < ROWS * NTA; it += 8) {
-            const int r = it / NTA, nt = it - r * NTA;
-            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-            for (int dt = 0; dt < a.kta; ++dt) {
-                const int f = t + dt - pt;
-                if (f < 0 || f >= a.T) continue;
-                const char* xs = sm + ((f + kAbcRing) & (kAbcRing - 1)) * slot_bytes + (r * 16 + frow) * PB + fg * 16;
+        {
+            const int items = ROWS * NTA;
+            for (int pr = wave; 2 * pr < items; pr += 8) {
+                const bool two = 2 * pr + 1 < items;
+                const int i0 = 2 * pr, i1 = two ? i0 + 1 : i0;
+                const int r0 = i0 / NTA, n0 = i0 - r0 * NTA, r1 = i1 / NTA, n1 = i1 - r1 * NTA;
+                f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+                for (int blk = 0; blk < nba; ++blk) {
+                    // this lane's K-slot of the block: (tap dt, 8-channel part) -> frame t + dt - pt of the ring, or nothing
+                    const int sl = 4 * blk + fg, dt = sl / SPTA, part = sl - dt * SPTA, f = t + dt - pt;
+                    uint4 b0 = uint4{0u, 0u, 0u, 0u}, b1 = b0;
+                    if (sl < nsa && f >= 0 && f < a.T) {
+                        const char* xs = sm + ((f + kAbcRing) & (kAbcRing - 1)) * slot_bytes + frow * PBI + part * 16;
+                        b0 = *reinterpret_cast<const uint4*>(xs + r0 * 16 * PBI);
+                        b1 = *reinterpret_cast<const uint4*>(xs + r1 * 16 * PBI);
+                    }
+                    Mma<DT>::run(wfr[(blk * NTA + n0) * 64 + lane], b0, acc0);
+                    Mma<DT>::run(wfr[(blk * NTA + n1) * 64 + lane], b1, acc1);
+                }
+                const int ww = w0 - 1 + frow;
 #pragma unroll
-                for (int kb = 0; kb < KBA; ++kb)
-                    Mma<DT>::run(wfr[((dt * KBA + kb) * NTA + nt) * 64 + lane], *reinterpret_cast<const uint4*>(xs + kb * 64), acc);
-            }
-            const int hh = h0 - 1 + r, ww = w0 - 1 + frow, ch = nt * 16 + fg * 4;
-            const bool inside = (unsigned)hh < (unsigned)a.H && (unsigned)ww < (unsigned)a.W;
-            if (ch < INNER) {
-                const f32x4 s = *reinterpret_cast<const f32x4*>(bn + ch), h = *reinterpret_cast<const f32x4*>(bn + 32 + ch);
-                f32x4 v = acc * s + h;
+                for (int k = 0; k < 2; ++k) {
+                    const int r = k ? r1 : r0, ch = (k ? n1 : n0) * 16 + fg * 4, hh = h0 - 1 + r;
+                    const bool inside = (unsigned)hh < (unsigned)a.H && (unsigned)ww < (unsigned)a.W;
+                    if (ch < INNER && (k == 0 || two)) {
+                        const f32x4 s = *reinterpret_cast<const f32x4*>(bn + ch), h = *reinterpret_cast<const f32x4*>(bn + 32 + ch);
+                        f32x4 v = (k ? acc1 : acc0) * s + h;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = inside ? relu_f(v[e]) : 0.f;
-                Vec4<DT>::store(abuf + (17 + r * 16 + frow) * AB + ch * 2, v);
+                        for (int e = 0; e < 4; ++e) v[e] = inside ? relu_f(v[e]) : 0.f;
+                        Vec4<DT>::store(abuf + (17 + r * 16 + frow) * AB + ch * 2, v);
+                    }
+                }
             }
         }
         __syncthreads();
         // ---- b(t): 1 x 3 x 3 on rows 1 .. PH; K-slot s = 4 blk + fg = (tap, 8-channel part); a tap is a constant pixel shift
-        for (int it = wave; it < a.PH * NTA; it += 8) {
-            const int r = 1 + it / NTA, nt = it % NTA;
-            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        {
+            const int items = a.PH * NTA;
+            for (int pr = wave; 2 * pr < items; pr += 8) {
+                const bool two = 2 * pr + 1 < items;
+                const int i0 = 2 * pr, i1 = two ? i0 + 1 : i0;
+                const int r0 = 1 + i0 / NTA, n0 = i0 % NTA, r1 = 1 + i1 / NTA, n1 = i1 % NTA;
+                f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
 #pragma unroll
-            for (int blk = 0; blk < NBB; ++blk) {
-                const int s = 4 * blk + fg, tap = s / SPT, part = s - tap * SPT;
-                uint4 b = uint4{0u, 0u, 0u, 0u};
-                if (tap < 9) {
-                    const int dh = tap / 3, dw = tap - dh * 3;
-                    b = *reinterpret_cast<const uint4*>(abuf + (17 + (r + dh - 1) * 16 + frow + dw - 1) * AB + part * 16);
+                for (int blk = 0; blk < NBB; ++blk) {
+                    const int s = 4 * blk + fg, tap = s / SPT, part = s - tap * SPT;
+                    uint4 b0 = uint4{0u, 0u, 0u, 0u}, b1 = b0;
+                    if (tap < 9) {
+                        const int dh = tap / 3, dw = tap - dh * 3;
+                        const char* ab = abuf + (17 + (dh - 1) * 16 + frow + dw - 1) * AB + part * 16;
+                        b0 = *reinterpret_cast<const uint4*>(ab + r0 * 16 * AB);
+                        b1 = *reinterpret_cast<const uint4*>(ab + r1 * 16 * AB);
+                    }
+                    Mma<DT>::run(wfr[(nfa + blk * NTA + n0) * 64 + lane], b0, acc0);
+                    Mma<DT>::run(wfr[(nfa + blk * NTA + n1) * 64 + lane], b1, acc1);
                 }
-                Mma<DT>::run(wfr[(nfa + blk * NTA + nt) * 64 + lane], b, acc);
-            }
-            const int ch = nt * 16 + fg * 4;
-            if (ch < INNER) {
-                const f32x4 s = *reinterpret_cast<const f32x4*>(bn + 64 + ch), h = *reinterpret_cast<const f32x4*>(bn + 96 + ch);
-                f32x4 v = acc * s + h;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = relu_f(v[e]);
-                Vec4<DT>::store(bbuf + (r * 16 + frow) * AB + ch * 2, v);
+                for (int k = 0; k < 2; ++k) {
+                    const int r = k ? r1 : r0, ch = (k ? n1 : n0) * 16 + fg * 4;
+                    if (ch < INNER && (k == 0 || two)) {
+                        const f32x4 s = *reinterpret_cast<const f32x4*>(bn + 64 + ch), h = *reinterpret_cast<const f32x4*>(bn + 96 + ch);
+                        f32x4 v = (k ? acc1 : acc0) * s + h;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = relu_f(v[e]);
+                        Vec4<DT>::store(bbuf + (r * 16 + frow) * AB + ch * 2, v);
+                    }
+                }
             }
         }
         __syncthreads();
@@ -201,18 +245,45 @@ __global__ __launch_bounds__(512, 2) void block_abc_kernel(const ABCArgs a) {
         // past its store of y(t - 1): two barriers ago)
         {
             const char* xt = sm + ((t + kAbcRing) & (kAbcRing - 1)) * slot_bytes;
-            for (int it = wave; it < a.PH * NTC; it += 8) {
-                const int r = 1 + it / NTC, nt = it % NTC;
-                uint4 b = uint4{0u, 0u, 0u, 0u};
-                if (fg < SPT) b = *reinterpret_cast<const uint4*>(bbuf + (r * 16 + frow) * AB + fg * 16);
-                f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-                Mma<DT>::run(wfr[(nfa + nfb + nt) * 64 + lane], b, acc);
-                const int ch = nt * 16 + fg * 4;
-                const f32x4 s = *reinterpret_cast<const f32x4*>(bn + 128 + ch), h = *reinterpret_cast<const f32x4*>(bn + 128 + C + ch);
-                f32x4 v = acc * s + h + Vec4<DT>::load(xt + (r * 16 + frow) * PB + ch * 2);
+            const int items = a.PH * NTC;
+            for (int pr = wave; 2 * pr < items; pr += 8) {
+                const bool two = 2 * pr + 1 < items;
+                const int i0 = 2 * pr, i1 = two ? i0 + 1 : i0;
+                const int r0 = 1 + i0 / NTC, n0 = i0 % NTC, r1 = 1 + i1 / NTC, n1 = i1 % NTC;
+                uint4 b0 = uint4{0u, 0u, 0u, 0u}, b1 = b0;
+                if (fg < SPT) {
+                    b0 = *reinterpret_cast<const uint4*>(bbuf + (r0 * 16 + frow) * AB + fg * 16);
+                    b1 = *reinterpret_cast<const uint4*>(bbuf + (r1 * 16 + frow) * AB + fg * 16);
+                }
+                const int c0 = n0 * 16 + fg * 4, c1 = n1 * 16 + fg * 4;
+                f32x4 x0 = f32x4{0.f, 0.f, 0.f, 0.f}, x1 = x0;                // identity shortcut: the trunk pixel's own channels
+                if (!PROJ) { x0 = Vec4<DT>::load(xt + (r0 * 16 + frow) * PBI + c0 * 2); x1 = Vec4<DT>::load(xt + (r1 * 16 + frow) * PBI + c1 * 2); }
+                f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+                Mma<DT>::run(wfr[(nfa + nfb + n0) * 64 + lane], b0, acc0);
+                Mma<DT>::run(wfr[(nfa + nfb + n1) * 64 + lane], b1, acc1);
+                if (PROJ) {                                                  // projection shortcut: a second K segment over x(t)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = relu_f(v[e]);
-                Vec4<DT>::store(ybuf + ((r - 1) * 16 + frow) * PB + ch * 2, v);
+                    for (int blk = 0; blk < NB1; ++blk) {
+                        const int sl = 4 * blk + fg;
+                        uint4 p0 = uint4{0u, 0u, 0u, 0u}, p1 = p0;
+                        if (sl < SPTA) {
+                            p0 = *reinterpret_cast<const uint4*>(xt + (r0 * 16 + frow) * PBI + sl * 16);
+                            p1 = *reinterpret_cast<const uint4*>(xt + (r1 * 16 + frow) * PBI + sl * 16);
+                        }
+                        Mma<DT>::run(wfr[(nfa + nfb + NTC + blk * NTC + n0) * 64 + lane], p0, acc0);
+                        Mma<DT>::run(wfr[(nfa + nfb + NTC + blk * NTC + n1) * 64 + lane], p1, acc1);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    if (k == 1 && !two) break;
+                    const int r = k ? r1 : r0, ch = k ? c1 : c0;
+                    const f32x4 s = *reinterpret_cast<const f32x4*>(bn + 128 + ch), h = *reinterpret_cast<const f32x4*>(bn + 128 + C + ch);
+                    f32x4 v = (k ? acc1 : acc0) * s + h + (k ? x1 : x0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = relu_f(v[e]);
+                    Vec4<DT>::store(ybuf + ((r - 1) * 16 + frow) * PB + ch * 2, v);
+                }
             }
         }
     }
@@ -220,15 +291,23 @@ __global__ __launch_bounds__(512, 2) void block_abc_kernel(const ABCArgs a) {
     if (t1 > t0) store_frame(t1 - 1);
 }
 
-// patch rows / time segments for a layer; false: the block does not take this path
-static bool abc_geometry(const af_conv_desc* da, const af_conv_desc* db, const af_conv_desc* dc, int* ph, int* ts_n) {
+// patch rows / time segments for a layer; false: the block does not take this path.  d1 != null: block 0 of a stage with a
+// 1x1x1 stride-1 projection shortcut over the block's input (cin = d1->cin channels)
+static bool abc_geometry(const af_conv_desc* da, const af_conv_desc* db, const af_conv_desc* dc, const af_conv_desc* d1, int* ph, int* ts_n) {
     if (!da || !db || !dc) return false;
     if (da->dtype == AF_F32 || db->dtype != da->dtype || dc->dtype != da->dtype) return false;
-    const int inner = da->cout;
+    const int inner = da->cout, cin = da->cin;
     // (inner 32 - s4 of the Fast pathway - runs and is parity-tested, but its 50 KB of weight fragments leave room for 3-row patches
     //  only and it measured 0.082 ms against 0.075 for the three launches: offered only with AF_ABC_INNER32=1)
     if (inner == 32 && !(getenv("AF_ABC_INNER32") && atoi(getenv("AF_ABC_INNER32")))) return false;
-    if ((inner != 8 && inner != 16 && inner != 32) || da->cin != 4 * inner || db->cin != inner || db->cout != inner || dc->cin != inner || dc->cout != 4 * inner) return false;
+    if ((inner != 8 && inner != 16 && inner != 32) || db->cin != inner || db->cout != inner || dc->cin != inner || dc->cout != 4 * inner) return false;
+    if (d1) {   // projection form: instantiated for the Fast pathway's s2 (8 -> 8 -> 8 -> 32)
+        if (inner != 8 || cin != 8 || d1->dtype != da->dtype || d1->cin != cin || d1->cout != dc->cout) return false;
+        if (d1->kt != 1 || d1->kh != 1 || d1->kw != 1 || d1->st != 1 || d1->sh != 1 || d1->sw != 1 || d1->pt || d1->ph || d1->pw || d1->tpool) return false;
+        if (d1->n != da->n || d1->t != da->t || d1->h != da->h || d1->w != da->w) return false;
+    } else if (cin != 4 * inner) {
+        return false;
+    }
     if ((da->kt != 1 && da->kt != 3) || da->kh != 1 || da->kw != 1 || da->pt != da->kt / 2 || da->ph || da->pw) return false;
     if (db->kt != 1 || db->kh != 3 || db->kw != 3 || db->pt || db->ph != 1 || db->pw != 1) return false;
     if (dc->kt != 1 || dc->kh != 1 || dc->kw != 1 || dc->pt || dc->ph || dc->pw) return false;
@@ -247,9 +326,9 @@ static bool abc_geometry(const af_conv_desc* da, const af_conv_desc* db, const a
     int p = eph ? atoi(eph) : 7;
     if (p > da->h) p = da->h;
     if (p < 1) p = 1;
-    while (p > 1 && abc_lds_bytes(inner, p, da->kt) > 160 * 1024) --p;
+    while (p > 1 && abc_lds_bytes(inner, cin, p, da->kt) > 160 * 1024) --p;
     p = (da->h + (da->h + p - 1) / p - 1) / ((da->h + p - 1) / p);                  // even bands
-    if (abc_lds_bytes(inner, p, da->kt) > 160 * 1024 || (p + 2) * (inner / 8) > 24) return false;   // <= 6 DMA pieces per producer wave and frame
+    if (abc_lds_bytes(inner, cin, p, da->kt) > 160 * 1024 || ((p + 2) * 16 * (cin / 8) + 63) / 64 > 24) return false;   // <= 6 DMA pieces per producer wave and frame
     const long long units = (long long)da->n * ((da->h + p - 1) / p) * ((da->w + 13) / 14);
     int s = 1;
     while (units * s < 256 && da->t / (2 * s) >= 4) s *= 2;           // time segments of >= 4 frames until the chip is covered
@@ -258,46 +337,49 @@ static bool abc_geometry(const af_conv_desc* da, const af_conv_desc* db, const a
     return true;
 }
 
-template <int DT, int INNER>
+template <int DT, int INNER, int CIN>
 static int launch_abc(const ABCArgs& a, int units, int lds, hipStream_t stream) {
-    AF_SET_MAX_LDS((&block_abc_kernel<DT, INNER>), 160 * 1024, "block_abc");
-    hipLaunchKernelGGL((block_abc_kernel<DT, INNER>), dim3(units), dim3(512), lds, stream, a);
+    AF_SET_MAX_LDS((&block_abc_kernel<DT, INNER, CIN>), 160 * 1024, "block_abc");
+    hipLaunchKernelGGL((block_abc_kernel<DT, INNER, CIN>), dim3(units), dim3(512), lds, stream, a);
     AF_CHECK_LAUNCH("block_abc_kernel");
     return AF_OK;
 }
 
 }  // namespace af
 
-extern "C" int af_block_abc_fusable(const af_conv_desc* da, const af_conv_desc* db, const af_conv_desc* dc) {
+extern "C" int af_block_abc_fusable(const af_conv_desc* da, const af_conv_desc* db, const af_conv_desc* dc, const af_conv_desc* d1) {
     int ph, ts;
-    return af::abc_geometry(da, db, dc, &ph, &ts) ? 1 : 0;
+    return af::abc_geometry(da, db, dc, d1, &ph, &ts) ? 1 : 0;
 }
 
 extern "C" int af_block_abc_bn_act(const af_conv_desc* da, const void* x, const void* wa_packed, const float* scale_a, const float* shift_a,
                                    const af_conv_desc* db, const void* wb_packed, const float* scale_b, const float* shift_b,
                                    const af_conv_desc* dc, const void* wc_packed, const float* scale_c, const float* shift_c,
-                                   void* out, int out_ld, void* stream) {
+                                   const af_conv_desc* d1, const void* w1_packed, void* out, int out_ld, void* stream) {
     using namespace af;
     AF_REQUIRE(da && db && dc && x && wa_packed && wb_packed && wc_packed && scale_a && shift_a && scale_b && shift_b && scale_c && shift_c && out,
                "block_abc: null argument");
-    AF_REQUIRE(aligned16(x) && aligned16(wa_packed) && aligned16(wb_packed) && aligned16(wc_packed) && aligned16(scale_a) && aligned16(shift_a) &&
-                   aligned16(scale_b) && aligned16(shift_b) && aligned16(scale_c) && aligned16(shift_c) && aligned16(out),
+    AF_REQUIRE((d1 != nullptr) == (w1_packed != nullptr), "block_abc: the projection shortcut needs both its descriptor and its weight");
+    AF_REQUIRE(aligned16(x) && aligned16(wa_packed) && aligned16(wb_packed) && aligned16(wc_packed) && aligned16(w1_packed) && aligned16(scale_a) &&
+                   aligned16(shift_a) && aligned16(scale_b) && aligned16(shift_b) && aligned16(scale_c) && aligned16(shift_c) && aligned16(out),
                "block_abc: buffers must be 16-byte aligned");
     int ph = 0, ts_n = 0;
-    AF_REQUIRE(abc_geometry(da, db, dc, &ph, &ts_n), "block_abc: this (a, b, c) triple does not take the fused path (ask af_block_abc_fusable first)");
+    AF_REQUIRE(abc_geometry(da, db, dc, d1, &ph, &ts_n), "block_abc: this block does not take the fused path (ask af_block_abc_fusable first)");
     if (out_ld == 0) out_ld = dc->cout;
     AF_REQUIRE(out_ld >= dc->cout && out_ld % 8 == 0, "block_abc: bad out_ld %d", out_ld);
     AF_REQUIRE(x != out, "block_abc: in-place is not possible (neighbouring patches read each other's halo)");
     ABCArgs a;
-    a.x = (const char*)x; a.wa = (const char*)wa_packed; a.wb = (const char*)wb_packed; a.wc = (const char*)wc_packed;
+    a.x = (const char*)x; a.wa = (const char*)wa_packed; a.wb = (const char*)wb_packed; a.wc = (const char*)wc_packed; a.w1 = (const char*)w1_packed;
     a.sa = scale_a; a.ha = shift_a; a.sb = scale_b; a.hb = shift_b; a.sc = scale_c; a.hc = shift_c;
     a.y = (char*)out; a.T = da->t; a.H = da->h; a.W = da->w; a.kta = da->kt; a.PH = ph;
     a.py_n = (da->h + ph - 1) / ph; a.px_n = (da->w + 13) / 14; a.ts_n = ts_n; a.TS = (da->t + ts_n - 1) / ts_n;
     a.out_ld = out_ld;
     const int units = da->n * a.py_n * a.px_n * a.ts_n;
-    const int lds = abc_lds_bytes(da->cout, ph, da->kt);
+    const int lds = abc_lds_bytes(da->cout, da->cin, ph, da->kt);
     hipStream_t s = (hipStream_t)stream;
-    if (da->cout == 8) return da->dtype == AF_BF16 ? launch_abc<AF_BF16, 8>(a, units, lds, s) : launch_abc<AF_F16, 8>(a, units, lds, s);
-    if (da->cout == 32) return da->dtype == AF_BF16 ? launch_abc<AF_BF16, 32>(a, units, lds, s) : launch_abc<AF_F16, 32>(a, units, lds, s);
-    return da->dtype == AF_BF16 ? launch_abc<AF_BF16, 16>(a, units, lds, s) : launch_abc<AF_F16, 16>(a, units, lds, s);
+    const bool bf = da->dtype == AF_BF16;
+    if (d1) return bf ? launch_abc<AF_BF16, 8, 8>(a, units, lds, s) : launch_abc<AF_F16, 8, 8>(a, units, lds, s);
+    if (da->cout == 8) return bf ? launch_abc<AF_BF16, 8, 32>(a, units, lds, s) : launch_abc<AF_F16, 8, 32>(a, units, lds, s);
+    if (da->cout == 32) return bf ? launch_abc<AF_BF16, 32, 128>(a, units, lds, s) : launch_abc<AF_F16, 32, 128>(a, units, lds, s);
+    return bf ? launch_abc<AF_BF16, 16, 64>(a, units, lds, s) : launch_abc<AF_F16, 16, 64>(a, units, lds, s);
 }

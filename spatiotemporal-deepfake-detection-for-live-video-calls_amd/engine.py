@@ -201,20 +201,24 @@ class _Plan:
         return bool(lib.af_conv_ca_fusable(C.byref(d1), C.byref(d3) if branch1 is not None else None, C.byref(d2)))
 
     def abc_fusable(self, blk, d) -> bool:
-        """does the library run this whole identity-shortcut block (a, b, c + residual + ReLU) as one launch
+        """does the library run this whole block (a, b, c + identity or stride-1 projection shortcut + ReLU) as one launch
         (af_block_abc_bn_act: the narrow blocks of SlowFast's Fast pathway)?  AF_FUSE_ABC=0 switches it off (A/B runs)."""
-        if self.code is None or os.environ.get("AF_FUSE_ABC", "1") != "1" or blk.branch1 is not None:
+        if self.code is None or os.environ.get("AF_FUSE_ABC", "1") != "1":
             return False
-        if any(cv.pool_after_bn is not None for cv in (blk.a, blk.b, blk.c)):
+        if any(cv is not None and cv.pool_after_bn is not None for cv in (blk.a, blk.b, blk.c, blk.branch1)):
             return False
         da = blk.a.out_dims(*d)
         db = blk.b.out_dims(*da)
         dc = blk.c.out_dims(*db)
-        d1, d2, d3 = _lib.ConvDesc(), _lib.ConvDesc(), _lib.ConvDesc()
+        d1, d2, d3, d4 = _lib.ConvDesc(), _lib.ConvDesc(), _lib.ConvDesc(), _lib.ConvDesc()
         _fill_conv_desc(d1, self.batch, self.code, blk.a, d, da, True)
         _fill_conv_desc(d2, self.batch, self.code, blk.b, da, db, True)
         _fill_conv_desc(d3, self.batch, self.code, blk.c, db, dc, True)
-        return bool(lib.af_block_abc_fusable(C.byref(d1), C.byref(d2), C.byref(d3)))
+        if blk.branch1 is not None:
+            if blk.branch1.out_dims(*d) != dc:
+                return False
+            _fill_conv_desc(d4, self.batch, self.code, blk.branch1, d, dc, True)
+        return bool(lib.af_block_abc_fusable(C.byref(d1), C.byref(d2), C.byref(d3), C.byref(d4) if blk.branch1 is not None else None))
 
     def stage(self, stage, d, cur, nxt, a_buf, b_buf, last_ld=None, tpool_last=False):
         """One pathway's ResStage.  ``last_ld``: row stride of the stage's final output (room for the lateral's
@@ -227,7 +231,7 @@ class _Plan:
             if not a_done and not (tpool_last and last) and self.abc_fusable(blk, d):
                 # the whole block in one launch (narrow pathway): trunk in, trunk out, a and b stay on the CU
                 ld = last_ld if (last and last_ld) else blk.c.cout
-                self.add(kind="abc", cv=blk.a, cv2=blk.b, cv3=blk.c, din=d, dout=d, src=cur, dst=nxt, ld=ld)
+                self.add(kind="abc", cv=blk.a, cv2=blk.b, cv3=blk.c, cv4=blk.branch1, din=d, dout=d, src=cur, dst=nxt, ld=ld)
                 self.need(nxt, d, ld)
                 cur, nxt = nxt, cur
                 c = blk.c.cout
@@ -536,11 +540,19 @@ class Engine:
                                                  weights.shift[cva.conv].data_ptr())
                 op.weight2, op.scale2, op.shift2 = (weights.w[cvb.conv].data_ptr(), weights.scale[cvb.conv].data_ptr(),
                                                     weights.shift[cvb.conv].data_ptr())
-                op.weight3, op.scale3, op.shift3 = (weights.w[cvc.conv].data_ptr(), weights.scale[cvc.conv].data_ptr(),
-                                                    weights.shift[cvc.conv].data_ptr())
+                macs = cva.macs(*e["din"]) + cvb.macs(*e["din"]) + cvc.macs(*e["din"])
+                if e.get("cv4") is not None:                 # projection block: folded weights, scale = ones, summed shifts
+                    cv1 = e["cv4"]
+                    fill_conv(op.conv4, cv1, e["din"], e["din"], True)
+                    op.weight3, op.weight4 = weights.w_folded[cvc.conv].data_ptr(), weights.w_folded[cv1.conv].data_ptr()
+                    op.scale3, op.shift3 = weights.ones[cvc.conv].data_ptr(), weights.shift_sum[cvc.conv].data_ptr()
+                    macs += cv1.macs(*e["din"])
+                else:
+                    op.weight3, op.scale3, op.shift3 = (weights.w[cvc.conv].data_ptr(), weights.scale[cvc.conv].data_ptr(),
+                                                        weights.shift[cvc.conv].data_ptr())
                 op.out_ld = e.get("ld", cvc.cout)
-                self.op_names.append(cva.conv.rsplit(".", 1)[0] + ".a+b+c")
-                self.op_macs.append(batch * (cva.macs(*e["din"]) + cvb.macs(*e["din"]) + cvc.macs(*e["din"])))
+                self.op_names.append(cva.conv.rsplit(".", 1)[0] + ".a+b+c" + ("+branch1" if e.get("cv4") is not None else ""))
+                self.op_macs.append(batch * macs)
             elif kind == "bc":
                 cvb, cvc = e["cv"], e["cv2"]
                 op.kind, op.tag = _lib.AF_OP_CONV_BC, TAG_CONV_BC

@@ -110,29 +110,49 @@ def conv_bc(x_ndhwc, wb_oidhw, bn_b, wc_oidhw, bn_c, residual, dtype):
     return out
 
 
-def block_abc(x_ndhwc, wa_oidhw, bn_a, wb_oidhw, bn_b, wc_oidhw, bn_c, dtype, out_ld=0):
-    """relu(x + bn_c(c(relu(bn_b(b(relu(bn_a(a(x)))))))))  as one af_block_abc_bn_act launch (a: kT x 1 x 1, b: 1x3x3, c: 1x1x1);
-    None if the library does not fuse this triple (af_block_abc_fusable)."""
+def _pack_scaled(w_oidhw, scale, dtype):
+    """BN scale folded into the packed weight in fp32, before the one rounding (af_pack_conv_weight_scaled)"""
     L = lib()
     code = L.DTYPE_CODES[dtype]
-    n, t, h, w, ctrunk = x_ndhwc.shape
-    inner, kta = wa_oidhw.shape[0], wa_oidhw.shape[2]
-    da, db, dc = L.ConvDesc(), L.ConvDesc(), L.ConvDesc()
-    for d, (ci, co, k, p) in zip((da, db, dc), ((ctrunk, inner, (kta, 1, 1), (kta // 2, 0, 0)), (inner, inner, (1, 3, 3), (0, 1, 1)),
-                                                (inner, wc_oidhw.shape[0], (1, 1, 1), (0, 0, 0)))):
+    cout, cin, kt, kh, kw = w_oidhw.shape
+    wsrc = w_oidhw.float().cuda().contiguous()
+    nbytes = L.lib.af_packed_conv_weight_bytes(cout, cin, kt, kh, kw, code)
+    packed = torch.empty(nbytes // (4 if dtype == "f32" else 2), dtype=TORCH_DT[dtype], device="cuda")
+    L.check(L.lib.af_pack_conv_weight_scaled(_p(wsrc), _p(scale), cout, cin, kt, kh, kw, code, _p(packed), _stream()), "pack_conv_weight_scaled")
+    torch.cuda.current_stream().synchronize()
+    return packed
+
+
+def block_abc(x_ndhwc, wa_oidhw, bn_a, wb_oidhw, bn_b, wc_oidhw, bn_c, dtype, out_ld=0, w1_oidhw=None, bn_1=None):
+    """relu(shortcut(x) + bn_c(c(relu(bn_b(b(relu(bn_a(a(x)))))))))  as one af_block_abc_bn_act launch (a: kT x 1 x 1, b: 1x3x3,
+    c: 1x1x1; shortcut = x, or bn_1(conv1x1x1_1(x)) with w1 / bn_1: the projection form with folded weights); None if the
+    library does not fuse this block (af_block_abc_fusable)."""
+    L = lib()
+    code = L.DTYPE_CODES[dtype]
+    n, t, h, w, cin = x_ndhwc.shape
+    inner, kta, cout = wa_oidhw.shape[0], wa_oidhw.shape[2], wc_oidhw.shape[0]
+    da, db, dc, d1 = L.ConvDesc(), L.ConvDesc(), L.ConvDesc(), L.ConvDesc()
+    for d, (ci, co, k, p) in zip((da, db, dc, d1), ((cin, inner, (kta, 1, 1), (kta // 2, 0, 0)), (inner, inner, (1, 3, 3), (0, 1, 1)),
+                                                    (inner, cout, (1, 1, 1), (0, 0, 0)), (cin, cout, (1, 1, 1), (0, 0, 0)))):
         d.n, d.t, d.h, d.w, d.cin, d.cout = n, t, h, w, ci, co
         d.kt, d.kh, d.kw = k
         d.st = d.sh = d.sw = 1
         d.pt, d.ph, d.pw = p
         d.to, d.ho, d.wo, d.relu, d.dtype = t, h, w, 1, code
-    if not L.lib.af_block_abc_fusable(C.byref(da), C.byref(db), C.byref(dc)):
+    proj = w1_oidhw is not None
+    if not L.lib.af_block_abc_fusable(C.byref(da), C.byref(db), C.byref(dc), C.byref(d1) if proj else None):
         return None
-    pa, pb, pc = _pack_plain(wa_oidhw, dtype), _pack_plain(wb_oidhw, dtype), _pack_plain(wc_oidhw, dtype)
-    ld = out_ld or wc_oidhw.shape[0]
+    pa, pb = _pack_plain(wa_oidhw, dtype), _pack_plain(wb_oidhw, dtype)
+    if proj:
+        pc, p1 = _pack_scaled(wc_oidhw, bn_c[0], dtype), _pack_scaled(w1_oidhw, bn_1[0], dtype)
+        sc3, sh3 = torch.ones_like(bn_c[0]), (bn_c[1] + bn_1[1]).contiguous()
+    else:
+        pc, p1, sc3, sh3 = _pack_plain(wc_oidhw, dtype), None, bn_c[0], bn_c[1]
+    ld = out_ld or cout
     out = torch.full((n, t, h, w, ld), 7.0, dtype=TORCH_DT[dtype], device="cuda")
     L.check(L.lib.af_block_abc_bn_act(C.byref(da), _p(x_ndhwc), _p(pa), _p(bn_a[0]), _p(bn_a[1]), C.byref(db), _p(pb), _p(bn_b[0]),
-                                      _p(bn_b[1]), C.byref(dc), _p(pc), _p(bn_c[0]), _p(bn_c[1]), _p(out), out_ld, _stream()),
-            "block_abc_bn_act")
+                                      _p(bn_b[1]), C.byref(dc), _p(pc), _p(sc3), _p(sh3), C.byref(d1) if proj else None, _p(p1),
+                                      _p(out), out_ld, _stream()), "block_abc_bn_act")
     torch.cuda.current_stream().synchronize()
     return out
 

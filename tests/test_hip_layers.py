@@ -549,6 +549,36 @@ def test_fused_block_a_b_c_vs_oracle(name, inner, kta, dims, out_ld, dtype, monk
 
 
 @pytest.mark.parametrize("dtype", ["f16", "bf16"])
+@pytest.mark.parametrize("dims", [(2, 12, 56, 56), (1, 7, 33, 30)])
+def test_fused_projection_block_vs_oracle(dims, dtype):
+    """af_block_abc_bn_act, projection form (block 0 of the Fast pathway's s2): x has 8 channels, a: 3x1x1 8 -> 8 (all three
+    taps in one K-block), b: 1x3x3, c: 1x1x1 8 -> 32 and the shortcut 1x1x1 8 -> 32 share one accumulator (BN scales folded into
+    both packed weights, shifts summed); against four oracle conv_bn_act calls in fp64."""
+    seed = 6500 + dims[2]
+    lay = [("a.weight", (8, 8, 3, 1, 1), "float32"), ("b.weight", (8, 8, 1, 3, 3), "float32"), ("c.weight", (32, 8, 1, 1, 1), "float32"),
+           ("s.weight", (32, 8, 1, 1, 1), "float32")]
+    for p_, ch in (("a_bn", 8), ("b_bn", 8), ("c_bn", 32), ("s_bn", 32)):
+        lay += [(p_ + s_, (ch,), "float32") for s_ in (".weight", ".bias", ".running_mean", ".running_var")]
+    sd = synth.fill_layout(lay, seed)
+    tdt = hh.TORCH_DT[dtype]
+    x = synth.synthetic_tensor((dims[0], 8) + dims[1:], seed).to(tdt).float()
+    for k in ("a.weight", "b.weight"):
+        sd[k] = sd[k].to(tdt).float()
+    sd64 = {k: v.double() for k, v in sd.items()}
+    ya = oracle.conv_bn_act(x.double(), sd64["a.weight"], sd64, "a_bn", (1, 1, 1), (1, 0, 0), True).to(tdt).double()
+    yb = oracle.conv_bn_act(ya, sd64["b.weight"], sd64, "b_bn", (1, 1, 1), (0, 1, 1), True).to(tdt).double()
+    want = F.relu(oracle.conv_bn_act(yb, sd64["c.weight"], sd64, "c_bn", (1, 1, 1), (0, 0, 0), False) +
+                  oracle.conv_bn_act(x.double(), sd64["s.weight"], sd64, "s_bn", (1, 1, 1), (0, 0, 0), False))
+    got = hh.block_abc(hh.to_ndhwc(x, dtype), sd["a.weight"], hh.fold_bn(sd, "a_bn"), sd["b.weight"], hh.fold_bn(sd, "b_bn"),
+                       sd["c.weight"], hh.fold_bn(sd, "c_bn"), dtype, w1_oidhw=sd["s.weight"], bn_1=hh.fold_bn(sd, "s_bn"))
+    assert got is not None, "the library should fuse this block"
+    got = hh.to_ncdhw(got).double()
+    tol = {"f16": 4e-3, "bf16": 3e-2}[dtype]       # folded weights: one more rounding of each c / shortcut weight than the oracle's
+    err = (got - want).abs().max().item()
+    assert err <= tol * (want.abs().max().item() + 1e-9), "proj %s[%s] err %.3e" % (dims, dtype, err)
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
 @pytest.mark.parametrize("name,ctrunk,dims", [
     ("s2_like_T32", 256, (2, 32, 64, 66)),        # T = 32: 8 pixels per tile, 4 K slabs; 1 056 tiles >= 4 per CU
     ("T16_two_slabs", 128, (3, 16, 76, 76)),      # T = 16: 16 pixels per tile, 2 K slabs, 1 083 tiles
