@@ -38,7 +38,7 @@ struct ABCArgs {
     int out_ld;
 };
 
-constexpr int kAbcRing = 4;
+constexpr int kAbcRing = 4;         // frames t - 1 .. t + 1 in use, t + 2 in flight (six slots + a two-step prefetch measured 8 % slower)
 
 template <int INNER, int CIN> struct AbcDims {
     static constexpr int C = 4 * INNER;                // trunk channels out (= CIN for an identity-shortcut block)
@@ -59,7 +59,7 @@ static inline int abc_lds_bytes(int inner, int cin, int ph, int kta) {
     const int C = 4 * inner, PB = C * 2, PBI = cin * 2, AB = inner * 2, rows = ph + 2;
     const int nta = (inner + 15) / 16;
     const int nfrag = ((kta * (cin / 8) + 3) / 4 + (9 * (inner / 8) + 3) / 4) * nta + C / 16 * (1 + (cin != C ? (cin / 8 + 3) / 4 : 0));
-    return kAbcRing * rows * 16 * PBI + (rows * 16 + 34) * AB + rows * 16 * AB + ph * 16 * PB + nfrag * 1024 + (2 * 32 + 2 * 32 + 2 * C) * 4;
+    return kAbcRing * ((rows * 16 * PBI + 1023) & ~1023) + (rows * 16 + 34) * AB + rows * 16 * AB + ph * 16 * PB + nfrag * 1024 + (2 * 32 + 2 * 32 + 2 * C) * 4;
 }
 
 template <int DT, int INNER, int CIN>
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(512, 2) void block_abc_kernel(const ABCArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int frow = lane & 15, fg = lane >> 4;
     const int ROWS = a.PH + 2;
-    const int slot_bytes = ROWS * 16 * PBI;
+    const int slot_bytes = (ROWS * 16 * PBI + 1023) & ~1023;         // whole DMA pieces: a piece's lanes beyond the patch write zeros
     char* abuf = sm + kAbcRing * slot_bytes;                       // a(t): haloed pixel p at entry 17 + p (guards: taps of dropped columns)
     char* bbuf = abuf + (ROWS * 16 + 34) * AB;                     // b(t)
     char* ybuf = bbuf + ROWS * 16 * AB;                            // y(t): rows 1 .. PH of the haloed patch
@@ -167,123 +167,97 @@ __global__ __launch_bounds__(512, 2) void block_abc_kernel(const ABCArgs a) {
         if (t + 2 <= f_hi) issue_frame(t + 2);                         // its slot held frame t - 2: dead since a(t - 1)
         if (t > t0) store_frame(t - 1);                                // under this frame's a phase
 
-        // Every phase hands a wave its tiles in PAIRS with two independent accumulators: a tile is a dependent chain (LDS read ->
-        // MFMA -> ... -> BN -> LDS write, ~350 cycles of latency for a few dozen of issue), two interleaved chains cost little
-        // more than one (the second tile of an odd count is clamped onto the first and not written back).
+        // (Handing a wave its tiles in pairs with two interleaved accumulators was tried and measured 5 - 20 % slower: the clamped
+        //  second tile of an odd count is redundant work and the phases are short enough that wave-level parallelism wins.)
         // ---- a(t): kT x 1 x 1 over the haloed patch, one row of 16 pixels per MFMA tile
-        {
-            const int items = ROWS * NTA;
-            for (int pr = wave; 2 * pr < items; pr += 8) {
-                const bool two = 2 * pr + 1 < items;
-                const int i0 = 2 * pr, i1 = two ? i0 + 1 : i0;
-                const int r0 = i0 / NTA, n0 = i0 - r0 * NTA, r1 = i1 / NTA, n1 = i1 - r1 * NTA;
-                f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+        for (int it = wave; it < ROWS * NTA; it += 8) {
+            const int r = it / NTA, nt = it - r * NTA;
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (SPTA >= 4) {
+                // whole K-blocks per tap: the tap's frame is uniform, a frame outside the clip is a skipped block
+                constexpr int KBA = SPTA / 4 > 0 ? SPTA / 4 : 1;
+                for (int dt = 0; dt < a.kta; ++dt) {
+                    const int f = t + dt - pt;
+                    if (f < 0 || f >= a.T) continue;
+                    const char* xs = sm + ((f + kAbcRing) & (kAbcRing - 1)) * slot_bytes + (r * 16 + frow) * PBI + fg * 16;
+#pragma unroll
+                    for (int kb = 0; kb < KBA; ++kb)
+                        Mma<DT>::run(wfr[((dt * KBA + kb) * NTA + nt) * 64 + lane], *reinterpret_cast<const uint4*>(xs + kb * 64), acc);
+                }
+            } else {
+                // narrow input (projection form, 8 channels): a K-block's four 16-byte slots are different taps - each lane group
+                // reads its own frame of the ring, or nothing
                 for (int blk = 0; blk < nba; ++blk) {
-                    // this lane's K-slot of the block: (tap dt, 8-channel part) -> frame t + dt - pt of the ring, or nothing
                     const int sl = 4 * blk + fg, dt = sl / SPTA, part = sl - dt * SPTA, f = t + dt - pt;
-                    uint4 b0 = uint4{0u, 0u, 0u, 0u}, b1 = b0;
-                    if (sl < nsa && f >= 0 && f < a.T) {
-                        const char* xs = sm + ((f + kAbcRing) & (kAbcRing - 1)) * slot_bytes + frow * PBI + part * 16;
-                        b0 = *reinterpret_cast<const uint4*>(xs + r0 * 16 * PBI);
-                        b1 = *reinterpret_cast<const uint4*>(xs + r1 * 16 * PBI);
-                    }
-                    Mma<DT>::run(wfr[(blk * NTA + n0) * 64 + lane], b0, acc0);
-                    Mma<DT>::run(wfr[(blk * NTA + n1) * 64 + lane], b1, acc1);
+                    uint4 b = uint4{0u, 0u, 0u, 0u};
+                    if (sl < nsa && f >= 0 && f < a.T)
+                        b = *reinterpret_cast<const uint4*>(sm + ((f + kAbcRing) & (kAbcRing - 1)) * slot_bytes + (r * 16 + frow) * PBI + part * 16);
+                    Mma<DT>::run(wfr[(blk * NTA + nt) * 64 + lane], b, acc);
                 }
-                const int ww = w0 - 1 + frow;
+            }
+            const int hh = h0 - 1 + r, ww = w0 - 1 + frow, ch = nt * 16 + fg * 4;
+            const bool inside = (unsigned)hh < (unsigned)a.H && (unsigned)ww < (unsigned)a.W;
+            if (ch < INNER) {
+                const f32x4 sv = *reinterpret_cast<const f32x4*>(bn + ch), hv = *reinterpret_cast<const f32x4*>(bn + 32 + ch);
+                f32x4 v = acc * sv + hv;
 #pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    const int r = k ? r1 : r0, ch = (k ? n1 : n0) * 16 + fg * 4, hh = h0 - 1 + r;
-                    const bool inside = (unsigned)hh < (unsigned)a.H && (unsigned)ww < (unsigned)a.W;
-                    if (ch < INNER && (k == 0 || two)) {
-                        const f32x4 s = *reinterpret_cast<const f32x4*>(bn + ch), h = *reinterpret_cast<const f32x4*>(bn + 32 + ch);
-                        f32x4 v = (k ? acc1 : acc0) * s + h;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = inside ? relu_f(v[e]) : 0.f;
-                        Vec4<DT>::store(abuf + (17 + r * 16 + frow) * AB + ch * 2, v);
-                    }
-                }
+                for (int e = 0; e < 4; ++e) v[e] = inside ? relu_f(v[e]) : 0.f;
+                Vec4<DT>::store(abuf + (17 + r * 16 + frow) * AB + ch * 2, v);
             }
         }
         __syncthreads();
         // ---- b(t): 1 x 3 x 3 on rows 1 .. PH; K-slot s = 4 blk + fg = (tap, 8-channel part); a tap is a constant pixel shift
-        {
-            const int items = a.PH * NTA;
-            for (int pr = wave; 2 * pr < items; pr += 8) {
-                const bool two = 2 * pr + 1 < items;
-                const int i0 = 2 * pr, i1 = two ? i0 + 1 : i0;
-                const int r0 = 1 + i0 / NTA, n0 = i0 % NTA, r1 = 1 + i1 / NTA, n1 = i1 % NTA;
-                f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+        for (int it = wave; it < a.PH * NTA; it += 8) {
+            const int r = 1 + it / NTA, nt = it % NTA;
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int blk = 0; blk < NBB; ++blk) {
-                    const int s = 4 * blk + fg, tap = s / SPT, part = s - tap * SPT;
-                    uint4 b0 = uint4{0u, 0u, 0u, 0u}, b1 = b0;
-                    if (tap < 9) {
-                        const int dh = tap / 3, dw = tap - dh * 3;
-                        const char* ab = abuf + (17 + (dh - 1) * 16 + frow + dw - 1) * AB + part * 16;
-                        b0 = *reinterpret_cast<const uint4*>(ab + r0 * 16 * AB);
-                        b1 = *reinterpret_cast<const uint4*>(ab + r1 * 16 * AB);
-                    }
-                    Mma<DT>::run(wfr[(nfa + blk * NTA + n0) * 64 + lane], b0, acc0);
-                    Mma<DT>::run(wfr[(nfa + blk * NTA + n1) * 64 + lane], b1, acc1);
+            for (int blk = 0; blk < NBB; ++blk) {
+                const int sl = 4 * blk + fg, tap = sl / SPT, part = sl - tap * SPT;
+                uint4 b = uint4{0u, 0u, 0u, 0u};
+                if (tap < 9) {
+                    const int dh = tap / 3, dw = tap - dh * 3;
+                    b = *reinterpret_cast<const uint4*>(abuf + (17 + (r + dh - 1) * 16 + frow + dw - 1) * AB + part * 16);
                 }
+                Mma<DT>::run(wfr[(nfa + blk * NTA + nt) * 64 + lane], b, acc);
+            }
+            const int ch = nt * 16 + fg * 4;
+            if (ch < INNER) {
+                const f32x4 sv = *reinterpret_cast<const f32x4*>(bn + 64 + ch), hv = *reinterpret_cast<const f32x4*>(bn + 96 + ch);
+                f32x4 v = acc * sv + hv;
 #pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    const int r = k ? r1 : r0, ch = (k ? n1 : n0) * 16 + fg * 4;
-                    if (ch < INNER && (k == 0 || two)) {
-                        const f32x4 s = *reinterpret_cast<const f32x4*>(bn + 64 + ch), h = *reinterpret_cast<const f32x4*>(bn + 96 + ch);
-                        f32x4 v = (k ? acc1 : acc0) * s + h;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = relu_f(v[e]);
-                        Vec4<DT>::store(bbuf + (r * 16 + frow) * AB + ch * 2, v);
-                    }
-                }
+                for (int e = 0; e < 4; ++e) v[e] = relu_f(v[e]);
+                Vec4<DT>::store(bbuf + (r * 16 + frow) * AB + ch * 2, v);
             }
         }
         __syncthreads();
-        // ---- c(t): 1 x 1 x 1 back to C channels, + the residual from the ring's frame t, ReLU -> the output tile (every wave is
-        // past its store of y(t - 1): two barriers ago)
+        // ---- c(t): 1 x 1 x 1 back to C channels, + the shortcut (the ring's frame t: its own channels, or the projection as a
+        // second K segment), ReLU -> the output tile (every wave is past its store of y(t - 1): two barriers ago)
         {
             const char* xt = sm + ((t + kAbcRing) & (kAbcRing - 1)) * slot_bytes;
-            const int items = a.PH * NTC;
-            for (int pr = wave; 2 * pr < items; pr += 8) {
-                const bool two = 2 * pr + 1 < items;
-                const int i0 = 2 * pr, i1 = two ? i0 + 1 : i0;
-                const int r0 = 1 + i0 / NTC, n0 = i0 % NTC, r1 = 1 + i1 / NTC, n1 = i1 % NTC;
-                uint4 b0 = uint4{0u, 0u, 0u, 0u}, b1 = b0;
-                if (fg < SPT) {
-                    b0 = *reinterpret_cast<const uint4*>(bbuf + (r0 * 16 + frow) * AB + fg * 16);
-                    b1 = *reinterpret_cast<const uint4*>(bbuf + (r1 * 16 + frow) * AB + fg * 16);
-                }
-                const int c0 = n0 * 16 + fg * 4, c1 = n1 * 16 + fg * 4;
-                f32x4 x0 = f32x4{0.f, 0.f, 0.f, 0.f}, x1 = x0;                // identity shortcut: the trunk pixel's own channels
-                if (!PROJ) { x0 = Vec4<DT>::load(xt + (r0 * 16 + frow) * PBI + c0 * 2); x1 = Vec4<DT>::load(xt + (r1 * 16 + frow) * PBI + c1 * 2); }
-                f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
-                Mma<DT>::run(wfr[(nfa + nfb + n0) * 64 + lane], b0, acc0);
-                Mma<DT>::run(wfr[(nfa + nfb + n1) * 64 + lane], b1, acc1);
-                if (PROJ) {                                                  // projection shortcut: a second K segment over x(t)
+            for (int it = wave; it < a.PH * NTC; it += 8) {
+                const int r = 1 + it / NTC, nt = it % NTC;
+                uint4 b = uint4{0u, 0u, 0u, 0u};
+                if (fg < SPT) b = *reinterpret_cast<const uint4*>(bbuf + (r * 16 + frow) * AB + fg * 16);
+                f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+                Mma<DT>::run(wfr[(nfa + nfb + nt) * 64 + lane], b, acc);
+                const int ch = nt * 16 + fg * 4;
+                f32x4 res = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (PROJ) {
 #pragma unroll
                     for (int blk = 0; blk < NB1; ++blk) {
                         const int sl = 4 * blk + fg;
-                        uint4 p0 = uint4{0u, 0u, 0u, 0u}, p1 = p0;
-                        if (sl < SPTA) {
-                            p0 = *reinterpret_cast<const uint4*>(xt + (r0 * 16 + frow) * PBI + sl * 16);
-                            p1 = *reinterpret_cast<const uint4*>(xt + (r1 * 16 + frow) * PBI + sl * 16);
-                        }
-                        Mma<DT>::run(wfr[(nfa + nfb + NTC + blk * NTC + n0) * 64 + lane], p0, acc0);
-                        Mma<DT>::run(wfr[(nfa + nfb + NTC + blk * NTC + n1) * 64 + lane], p1, acc1);
+                        uint4 p = uint4{0u, 0u, 0u, 0u};
+                        if (sl < SPTA) p = *reinterpret_cast<const uint4*>(xt + (r * 16 + frow) * PBI + sl * 16);
+                        Mma<DT>::run(wfr[(nfa + nfb + NTC + blk * NTC + nt) * 64 + lane], p, acc);
                     }
+                } else {
+                    res = Vec4<DT>::load(xt + (r * 16 + frow) * PBI + ch * 2);
                 }
+                const f32x4 sv = *reinterpret_cast<const f32x4*>(bn + 128 + ch), hv = *reinterpret_cast<const f32x4*>(bn + 128 + C + ch);
+                f32x4 v = acc * sv + hv + res;
 #pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    if (k == 1 && !two) break;
-                    const int r = k ? r1 : r0, ch = k ? c1 : c0;
-                    const f32x4 s = *reinterpret_cast<const f32x4*>(bn + 128 + ch), h = *reinterpret_cast<const f32x4*>(bn + 128 + C + ch);
-                    f32x4 v = (k ? acc1 : acc0) * s + h + (k ? x1 : x0);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = relu_f(v[e]);
-                    Vec4<DT>::store(ybuf + ((r - 1) * 16 + frow) * PB + ch * 2, v);
-                }
+                for (int e = 0; e < 4; ++e) v[e] = relu_f(v[e]);
+                Vec4<DT>::store(ybuf + ((r - 1) * 16 + frow) * PB + ch * 2, v);
             }
         }
     }
