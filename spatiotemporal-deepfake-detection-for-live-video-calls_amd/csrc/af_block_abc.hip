@@ -174,16 +174,27 @@ __global__ __launch_bounds__(512, 2) void block_abc_kernel(const ABCArgs a) {
             const int r = it / NTA, nt = it - r * NTA;
             f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
             if (SPTA >= 4) {
-                // whole K-blocks per tap: the tap's frame is uniform, a frame outside the clip is a skipped block
+                // whole K-blocks per tap: the tap's frame is uniform.  All fragments are read first (a frame outside the clip or a
+                // tap beyond kT reads frame t and is zeroed: no branch, ONE LDS round trip for the tile instead of one per tap),
+                // then the MFMAs run back to back
                 constexpr int KBA = SPTA / 4 > 0 ? SPTA / 4 : 1;
-                for (int dt = 0; dt < a.kta; ++dt) {
+                uint4 bx[3][KBA];
+#pragma unroll
+                for (int dt = 0; dt < 3; ++dt) {
                     const int f = t + dt - pt;
-                    if (f < 0 || f >= a.T) continue;
-                    const char* xs = sm + ((f + kAbcRing) & (kAbcRing - 1)) * slot_bytes + (r * 16 + frow) * PBI + fg * 16;
+                    const bool ok = dt < a.kta && f >= 0 && f < a.T;
+                    const char* xs = sm + (((ok ? f : t) + kAbcRing) & (kAbcRing - 1)) * slot_bytes + (r * 16 + frow) * PBI + fg * 16;
+#pragma unroll
+                    for (int kb = 0; kb < KBA; ++kb) {
+                        bx[dt][kb] = *reinterpret_cast<const uint4*>(xs + kb * 64);
+                        if (!ok) bx[dt][kb] = uint4{0u, 0u, 0u, 0u};
+                    }
+                }
+#pragma unroll
+                for (int dt = 0; dt < 3; ++dt)
 #pragma unroll
                     for (int kb = 0; kb < KBA; ++kb)
-                        Mma<DT>::run(wfr[((dt * KBA + kb) * NTA + nt) * 64 + lane], *reinterpret_cast<const uint4*>(xs + kb * 64), acc);
-                }
+                        Mma<DT>::run(wfr[(((dt < a.kta ? dt : 0) * KBA + kb) * NTA + nt) * 64 + lane], bx[dt][kb], acc);
             } else {
                 // narrow input (projection form, 8 channels): a K-block's four 16-byte slots are different taps - each lane group
                 // reads its own frame of the ring, or nothing
@@ -210,16 +221,18 @@ __global__ __launch_bounds__(512, 2) void block_abc_kernel(const ABCArgs a) {
         for (int it = wave; it < a.PH * NTA; it += 8) {
             const int r = 1 + it / NTA, nt = it % NTA;
             f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+            uint4 bb[NBB], wb[NBB];                                      // all fragments first: one LDS round trip per tile
 #pragma unroll
             for (int blk = 0; blk < NBB; ++blk) {
-                const int sl = 4 * blk + fg, tap = sl / SPT, part = sl - tap * SPT;
-                uint4 b = uint4{0u, 0u, 0u, 0u};
-                if (tap < 9) {
-                    const int dh = tap / 3, dw = tap - dh * 3;
-                    b = *reinterpret_cast<const uint4*>(abuf + (17 + (r + dh - 1) * 16 + frow + dw - 1) * AB + part * 16);
-                }
-                Mma<DT>::run(wfr[(nfa + blk * NTA + nt) * 64 + lane], b, acc);
+                const int sl = 4 * blk + fg, tap = sl < 9 * SPT ? sl / SPT : 4, part = sl < 9 * SPT ? sl - tap * SPT : 0;
+                const int dh = tap / 3, dw = tap - dh * 3;
+                bb[blk] = *reinterpret_cast<const uint4*>(abuf + (17 + (r + dh - 1) * 16 + frow + dw - 1) * AB + part * 16);
+                if (sl >= 9 * SPT) bb[blk] = uint4{0u, 0u, 0u, 0u};
+                wb[blk] = wfr[(nfa + blk * NTA + nt) * 64 + lane];
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int blk = 0; blk < NBB; ++blk) Mma<DT>::run(wb[blk], bb[blk], acc);
             const int ch = nt * 16 + fg * 4;
             if (ch < INNER) {
                 const f32x4 sv = *reinterpret_cast<const f32x4*>(bn + 64 + ch), hv = *reinterpret_cast<const f32x4*>(bn + 96 + ch);
