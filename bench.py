@@ -127,10 +127,10 @@ def roofline_report(eng, args, line, reps=5):
             cb, cc_ = op.conv, op.conv2
             pos = cb.n * cb.to * cb.ho * cb.wo
             eng_bytes[i] = es * (pos * cb.cin + pos * cc_.cout * (2 if op.residual else 1) + cb.cout * cb.cin * 9 + cc_.cout * cc_.cin)
-        elif op.kind in (_lib.AF_OP_CONV, _lib.AF_OP_STEM, _lib.AF_OP_CONV_DUAL, _lib.AF_OP_STEM_POOL, _lib.AF_OP_STEM3_POOL, _lib.AF_OP_TSTEM):
+        elif op.kind in (_lib.AF_OP_CONV, _lib.AF_OP_STEM, _lib.AF_OP_CONV_DUAL, _lib.AF_OP_STEM_POOL, _lib.AF_OP_STEM3_POOL, _lib.AF_OP_TSTEM, _lib.AF_OP_TSTEM_POOL3):
             cd = op.conv
             mm = cd.n * cd.to * cd.ho * cd.wo
-            if op.kind in (_lib.AF_OP_STEM_POOL, _lib.AF_OP_STEM3_POOL):          # only the pooled tensor is written
+            if op.kind in (_lib.AF_OP_STEM_POOL, _lib.AF_OP_STEM3_POOL, _lib.AF_OP_TSTEM_POOL3):          # only the pooled tensor is written
                 mm = cd.n * cd.to * ((cd.ho - 1) // 2 + 1) * ((cd.wo - 1) // 2 + 1)
             elif cd.tpool:
                 mm //= (4 if cd.tpool == 2 else 2)
@@ -159,9 +159,9 @@ def roofline_report(eng, args, line, reps=5):
             kname = "conv133g<b + c fused>"
         elif op.kind == _lib.AF_OP_BLOCK_ABC:
             kname = "block_abc<a + b + c of a narrow block>"
-        elif op.kind in (_lib.AF_OP_STEM, _lib.AF_OP_STEM_POOL, _lib.AF_OP_STEM3_POOL, _lib.AF_OP_TSTEM):
+        elif op.kind in (_lib.AF_OP_STEM, _lib.AF_OP_STEM_POOL, _lib.AF_OP_STEM3_POOL, _lib.AF_OP_TSTEM, _lib.AF_OP_TSTEM_POOL3):
             kname = {_lib.AF_OP_STEM: "stem_kernel", _lib.AF_OP_STEM_POOL: "stem_pool_kernel", _lib.AF_OP_STEM3_POOL: "stem3_pool_kernel",
-                     _lib.AF_OP_TSTEM: "tstem_kernel"}[op.kind]
+                     _lib.AF_OP_TSTEM: "tstem_kernel", _lib.AF_OP_TSTEM_POOL3: "tstem_pool3_kernel"}[op.kind]
         else:
             continue
         op_kernel[i] = kname

@@ -251,11 +251,16 @@ int af_linear_scores(const float* x, const float* w, const float* b, int rows, i
 /* Temporal stem: Conv3d(3->64,[kt,1,1],stride 1,pad [kt/2,0,0]) + BN + MaxPool3d((1,2,2)) + ReLU - what
  * `temporal_only_conv` (:207-288) makes of ResNetBasicStem's conv / bn (stem_helper.py:156-178); d describes the conv
  * with to/ho/wo = t, h/2, w/2 (the pool is fused).  stem_in: af_pack_input_* buffer; out: NDHWC [n][t][h/2][w/2][64].
- * The stem's own MaxPool3d([1,3,3],[1,2,2],[0,1,1]) follows as af_maxpool3d. */
+ * The stem's own MaxPool3d([1,3,3],[1,2,2],[0,1,1]) follows as af_maxpool3d - or rides along:
+ * af_tstem_conv_bn_pool_relu_maxpool (ABI 3, 16-bit) takes the same descriptor and writes the stem pool's output
+ * [n][t][(h/2-1)/2+1][(w/2-1)/2+1][64] directly (the half-resolution tensor never exists; i3d_temporal_var_fix_dropout_tt_cfg.py
+ * keeps ResNetBasicStem's pool_layer behind the converted conv / bn). */
 int af_pack_tstem_weight(const float* w_oidhw, int cout, int kt, int dtype, void* out, void* stream);
 long long af_packed_tstem_weight_bytes(int dtype);
 int af_tstem_conv_bn_pool_relu(const af_conv_desc* d, const void* stem_in, const void* w_packed, const float* scale,
                                const float* shift, void* out, void* stream);
+int af_tstem_conv_bn_pool_relu_maxpool(const af_conv_desc* d, const void* stem_in, const void* w_packed, const float* scale,
+                                       const float* shift, void* out, void* stream);
 
 /* TimeTransformer head (time_transformer.py:219-281), fp32.  The Linear layers are af_conv3d_bn_act over the token
  * rows (1x1x1, AF_F32, scale = ones, shift = bias, residual = the skip connection).
@@ -345,7 +350,9 @@ enum af_op_kind { AF_OP_STEM = 0, AF_OP_CONV = 1, AF_OP_MAXPOOL = 2, AF_OP_HEAD 
                   /* a narrow bottleneck block in one launch: conv / weight / scale / shift = a, conv2 / weight2 / scale2 / shift2 = b,
                      conv3 / weight3 / scale3 / shift3 = c, in = the trunk (input and residual), out, out_ld; projection form:
                      pool is unused, in2 == in and (conv4, weight4) = the shortcut conv (af_block_abc_bn_act) */
-                  AF_OP_BLOCK_ABC = 20 };
+                  AF_OP_BLOCK_ABC = 20,
+                  /* TSTEM with the stem's 1x3x3 / stride-2 max-pool fused behind it (af_tstem_conv_bn_pool_relu_maxpool) */
+                  AF_OP_TSTEM_POOL3 = 21 };
 
 typedef struct af_op {
     int32_t kind;                    /* af_op_kind */

@@ -9,7 +9,7 @@ LIB_PATH = os.environ.get("AF_HIP_LIB") or os.path.join(HERE, "libafhip.so")   #
 AF_F32, AF_BF16, AF_F16 = 0, 1, 2
 (AF_OP_STEM, AF_OP_CONV, AF_OP_MAXPOOL, AF_OP_HEAD, AF_OP_PACK_F32, AF_OP_PACK_U8, AF_OP_CONV_DUAL, AF_OP_STEM_POOL, AF_OP_AVGPOOL,
  AF_OP_LINEAR, AF_OP_TSTEM, AF_OP_TOKENS, AF_OP_LAYERNORM, AF_OP_ATTENTION, AF_OP_GELU, AF_OP_CONV_BC, AF_OP_PACK3_F32,
- AF_OP_PACK3_U8, AF_OP_STEM3_POOL, AF_OP_CONV_CA, AF_OP_BLOCK_ABC) = range(21)
+ AF_OP_PACK3_U8, AF_OP_STEM3_POOL, AF_OP_CONV_CA, AF_OP_BLOCK_ABC, AF_OP_TSTEM_POOL3) = range(22)
 AF_ABI_VERSION = 3
 STEM_PAD_T, STEM_PAD_H, STEM_PAD_W_LEFT, STEM_PAD_W_TOTAL, STEM_CPAD = 2, 3, 3, 8, 4
 
@@ -107,6 +107,7 @@ ABI = {
     "af_pack_tstem_weight": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "af_packed_tstem_weight_bytes": (C.c_longlong, [C.c_int]),
     "af_tstem_conv_bn_pool_relu": (C.c_int, [C.POINTER(ConvDesc)] + [C.c_void_p] * 6),
+    "af_tstem_conv_bn_pool_relu_maxpool": (C.c_int, [C.POINTER(ConvDesc)] + [C.c_void_p] * 6),
     "af_tokens_assemble": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p, C.c_void_p]),
     "af_layernorm": (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p,
                                C.c_longlong, C.c_void_p]),

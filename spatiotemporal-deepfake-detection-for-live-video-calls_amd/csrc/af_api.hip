@@ -76,6 +76,8 @@ static int run_one(const af_op& op, hipStream_t s) {
                                          op.conv.dtype, op.out, s);
         case AF_OP_TSTEM:
             return af_tstem_conv_bn_pool_relu(&op.conv, op.in, op.weight, op.scale, op.shift, op.out, s);
+        case AF_OP_TSTEM_POOL3:
+            return af_tstem_conv_bn_pool_relu_maxpool(&op.conv, op.in, op.weight, op.scale, op.shift, op.out, s);
         case AF_OP_TOKENS:       /* in = pooled, weight = cls token, scale = position embedding; pool.n = clips, pool.t = tokens, pool.c = dim */
             return af_tokens_assemble((const float*)op.in, (const float*)op.weight, op.scale, op.pool.n, op.pool.t, op.pool.c,
                                       (float*)op.out, s);

@@ -182,6 +182,159 @@ __global__ __launch_bounds__(256) void tstem_kernel(const TStemArgs a) {
     }
 }
 
+// The temporal stem WITH the stem's own MaxPool3d([1,3,3],[1,2,2],[0,1,1]) fused behind it (round 3, 16-bit):
+//     conv [kt,1,1] + BN -> MaxPool3d((1,2,2)) -> ReLU -> MaxPool3d((1,3,3), s (1,2,2), p (0,1,1))
+// A final pixel (qy, qx) is the max over rows 2qy-1 .. 2qy+1, columns 2qx-1 .. 2qx+1 of the half-resolution map, each of
+// whose pixels is the max over a 2x2 window of conv outputs: the max over the 6 x 6 conv positions (4qy-2 .. 4qy+3) x
+// (4qx-2 .. 4qx+3) (ReLU commutes with max; BN is monotonic per channel, so the raw max / min decides, as in tstem_kernel).
+// Windows overlap (stride 4, extent 6): 2.25x the conv positions are computed - the conv is one MFMA K-block per position
+// tile, ~60 GFLOP per launch in all - and in exchange the 822-MB half-resolution tensor is neither written nor read back
+// (tstem 0.41 ms + maxpool 0.23 ms before).  The pool's -inf padding is handled in the addressing: a window row / column
+// pair outside the half-resolution map is CLAMPED onto a valid one of the same window (a duplicate member changes no max).
+// Lane = (final pixel frow of a 16-pixel tile, k-group fg = taps 2fg, 2fg+1); per window row three 16-byte loads per
+// tap chunk (two adjacent conv pixels each); the next row's loads (the next tile's first row behind the last one: six rows,
+// an even count, so the two register sets stay static) are issued before this row's 24 MFMAs.
+struct TStemP3Args {
+    const char* in;
+    const char* w;
+    const float* scale;
+    const float* shift;
+    char* out;           // [N][T][Hq][Wq][64]
+    int T, Hp, Wp, Tp;
+    int H2, W2;          // half-resolution map (h / 2, w / 2)
+    int Hq, Wq;          // final map
+    int tiles_w;
+    long long tiles;     // N * T * Hq * tiles_w
+    int t_off, kt;
+};
+
+template <int DT>
+__global__ __launch_bounds__(256, 2) void tstem_pool3_kernel(const TStemP3Args a) {
+    typedef Elem<DT> E;
+    static_assert(E::EPC == 8, "16-bit operands only");
+    constexpr int PIXB = 8;                                   // bytes per padded pixel (4 channels)
+    const int lane = threadIdx.x & 63, frow = lane & 15, fg = lane >> 4;
+    const long long wave0 = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long long nwaves = (long long)gridDim.x * (blockDim.x >> 6);
+    uint4 wf[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wf[i] = reinterpret_cast<const uint4*>(a.w)[i * 64 + lane];
+    f32x4 sc[4], sf[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        sc[i] = *reinterpret_cast<const f32x4*>(a.scale + i * 16 + fg * 4);
+        sf[i] = *reinterpret_cast<const f32x4*>(a.shift + i * 16 + fg * 4);
+    }
+    const long long row_b = (long long)a.Wp * PIXB, plane_b = row_b * a.Hp;
+    __shared__ uint4 patch_all[4 * 128];
+    char* patch = reinterpret_cast<char*>(patch_all) + (threadIdx.x >> 6) * 2048;
+
+    // a tile: wave-uniform (clip, frame, row qy, column tile tw) -> scalar base of the frame's first conv row; per lane the byte
+    // offsets of its three clamped column pairs
+    struct Where { int tw, qy, t; long long n; const char* base; int coff[3]; };
+    auto locate = [&](unsigned tile_u) {
+        const unsigned tile = (unsigned)__builtin_amdgcn_readfirstlane((int)tile_u);
+        Where w;
+        w.tw = (int)(tile % (unsigned)a.tiles_w); unsigned q = tile / (unsigned)a.tiles_w;
+        w.qy = (int)(q % (unsigned)a.Hq); q /= (unsigned)a.Hq;
+        w.t = (int)(q % (unsigned)a.T); w.n = q / (unsigned)a.T;
+        int qx = w.tw * 16 + frow;
+        if (qx > a.Wq - 1) qx = a.Wq - 1;                      // ragged last tile: clamped, never stored
+        w.base = a.in + ((w.n * a.Tp + w.t + a.t_off) * plane_b) + (long long)AF_STEM_PAD_H * row_b + (long long)AF_STEM_PAD_W_LEFT * PIXB;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {                          // half-resolution column 2qx - 1 + j, clamped into the map
+            int c = 2 * qx - 1 + j;
+            c = c < 0 ? 0 : (c > a.W2 - 1 ? a.W2 - 1 : c);
+            w.coff[j] = 2 * c * PIXB + fg * 2 * (int)plane_b;  // conv columns 2c, 2c + 1 (one 16-byte load) of tap 2 fg
+        }
+        return w;
+    };
+    typedef u32x4 __attribute__((aligned(8))) u32x4_a8;
+    // window row dy of a tile: conv row 4qy - 2 + dy, clamped into the conv rows of the window's valid half-resolution rows
+    auto load_row = [&](const char* base, int qy, const int (&coff)[3], int dy, uint4 (&l)[3][2]) {
+        const int rlo = 2 * qy - 1 < 0 ? 0 : 2 * qy - 1, rhi = 2 * qy + 1 > a.H2 - 1 ? a.H2 - 1 : 2 * qy + 1;
+        int y = 4 * qy - 2 + dy;
+        y = y < 2 * rlo ? 2 * rlo : (y > 2 * rhi + 1 ? 2 * rhi + 1 : y);
+        const char* rowp = base + (long long)y * row_b;        // uniform
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int tp = 0; tp < 2; ++tp) {
+                l[j][tp] = uint4{0u, 0u, 0u, 0u};
+                if (fg * 2 + tp < a.kt) l[j][tp] = __builtin_bit_cast(uint4, *reinterpret_cast<const u32x4_a8*>(rowp + (unsigned)(coff[j] + tp * (int)plane_b)));
+            }
+    };
+    unsigned tile = (unsigned)wave0;
+    if (tile >= (unsigned)a.tiles) return;
+    Where cur = locate(tile);
+    uint4 rowc[3][2], rown[3][2];
+    load_row(cur.base, cur.qy, cur.coff, 0, rowc);
+    for (; tile < (unsigned)a.tiles; tile += (unsigned)nwaves) {
+        float mx[4][4], mn[4][4];
+        bool nanf[4][4];                                       // per output element: a member was NaN (-> NaN, like ATen's max_pool)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { mx[i][e] = -INFINITY; mn[i][e] = INFINITY; nanf[i][e] = false; }
+        const unsigned ntile = tile + (unsigned)nwaves < (unsigned)a.tiles ? tile + (unsigned)nwaves : tile;
+        const Where nxt = locate(ntile);
+#pragma unroll 1
+        for (int dy = 0; dy < 6; ++dy) {
+            // the next window row (behind the last one: row 0 of the next tile) is fetched while this one multiplies
+            if (dy < 5) load_row(cur.base, cur.qy, cur.coff, dy + 1, rown);
+            else load_row(nxt.base, nxt.qy, nxt.coff, 0, rown);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const uint4 &l0 = rowc[j][0], &l1 = rowc[j][1];
+                const uint4 blo = uint4{l0.x, l0.y, l1.x, l1.y}, bhi = uint4{l0.z, l0.w, l1.z, l1.w};
+                f32x4 lo[4], hi[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    lo[i] = f32x4{0.f, 0.f, 0.f, 0.f}; hi[i] = lo[i];
+                    Mma<DT>::run(wf[i], blo, lo[i]);
+                    Mma<DT>::run(wf[i], bhi, hi[i]);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float xl = lo[i][e], xh = hi[i][e];
+                        mx[i][e] = __builtin_fmaxf(mx[i][e], __builtin_fmaxf(xl, xh));     // (v_max3_f32: NaN operands are ignored,
+                        mn[i][e] = __builtin_fminf(mn[i][e], __builtin_fminf(xl, xh));     //  the flag below carries them)
+                        nanf[i][e] = nanf[i][e] || __builtin_isunordered(lo[i][e], hi[i][e]);
+                    }
+                __builtin_amdgcn_sched_barrier(0);                 // one pair's 8 accumulators live at a time
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { rowc[j][0] = rown[j][0]; rowc[j][1] = rown[j][1]; }
+        }
+        // BN on the deciding member (max for a scale >= 0, min below), NaN like ATen's max_pool, ReLU, 16 pixels x 128 B out
+        const long long opix0 = ((cur.n * a.T + cur.t) * a.Hq + cur.qy) * a.Wq + cur.tw * 16;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float y = (sc[i][e] >= 0.f ? mx[i][e] : mn[i][e]) * sc[i][e] + sf[i][e];
+                v[e] = relu_f(nanf[i][e] ? __builtin_nanf("") : y);
+            }
+            const int c = i * 2 + (fg >> 1);
+            Vec4<DT>::store(patch + frow * 128 + ((c ^ (frow & 7)) * 16) + (fg & 1) * 8, v);
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int p = it * 8 + (lane >> 3), c = lane & 7;
+            const uint4 o = *reinterpret_cast<const uint4*>(patch + p * 128 + ((c ^ (p & 7)) * 16));
+            if (cur.tw * 16 + p < a.Wq)
+                __builtin_nontemporal_store(__builtin_bit_cast(u32x4, o), reinterpret_cast<u32x4*>(a.out + ((opix0 + p) * 64 + c * 8) * 2));
+        }
+        __builtin_amdgcn_wave_barrier();
+        cur = nxt;
+    }
+}
+
 __global__ void pack_tstem_weight_kernel(const float* w, int kt, int dtype, char* out) {
     // out[kb][tile][lane][16 B]; lane = fg*16 + frow -> channel tile*16 + frow, chunk = taps tap0.. x 4 channels
     const int epc = dtype == AF_F32 ? 4 : 8, tpc = epc / 4, kbs = dtype == AF_F32 ? 2 : 1;
@@ -318,6 +471,36 @@ extern "C" int af_tstem_conv_bn_pool_relu(const af_conv_desc* d, const void* ste
         default: hipLaunchKernelGGL((tstem_kernel<AF_F16>), dim3((unsigned)blocks), dim3(256), 0, s, a); break;
     }
     AF_CHECK_LAUNCH("tstem_kernel");
+    return AF_OK;
+}
+
+extern "C" int af_tstem_conv_bn_pool_relu_maxpool(const af_conv_desc* d, const void* stem_in, const void* w_packed,
+                                                  const float* scale, const float* shift, void* out, void* stream) {
+    using namespace af;
+    AF_REQUIRE(d && stem_in && w_packed && scale && shift && out, "tstem_pool3: null argument");
+    AF_REQUIRE(d->dtype == AF_BF16 || d->dtype == AF_F16, "tstem_pool3: 16-bit dtypes only");
+    AF_REQUIRE(d->cin == 3 && d->cout == 64 && d->kh == 1 && d->kw == 1 && d->st == 1 && d->sh == 1 && d->sw == 1 &&
+                   d->ph == 0 && d->pw == 0, "tstem_pool3: expects Conv3d(3->64, [kt,1,1], stride 1)");
+    AF_REQUIRE(d->kt >= 1 && d->kt <= 2 * AF_STEM_PAD_T + 1 && (d->kt & 1) && d->pt == d->kt / 2, "tstem_pool3: bad kt/pt");
+    AF_REQUIRE(d->n > 0 && d->t > 0 && d->h >= 2 && d->w >= 2, "tstem_pool3: bad dims");
+    AF_REQUIRE(d->to == d->t && d->ho == d->h / 2 && d->wo == d->w / 2, "tstem_pool3: d describes the conv with the 2x2 pool (to, ho, wo = t, h/2, w/2)");
+    AF_REQUIRE(aligned16(stem_in) && aligned16(w_packed) && aligned16(scale) && aligned16(shift) && aligned16(out),
+               "tstem_pool3: buffers must be 16-byte aligned");
+    TStemP3Args a;
+    a.in = (const char*)stem_in; a.w = (const char*)w_packed; a.scale = scale; a.shift = shift; a.out = (char*)out;
+    a.T = d->t; a.Tp = d->t + 2 * AF_STEM_PAD_T; a.Hp = d->h + 2 * AF_STEM_PAD_H; a.Wp = d->w + AF_STEM_PAD_W_TOTAL;
+    a.H2 = d->ho; a.W2 = d->wo; a.Hq = (d->ho - 1) / 2 + 1; a.Wq = (d->wo - 1) / 2 + 1;
+    a.tiles_w = (a.Wq + 15) / 16;
+    a.tiles = (long long)d->n * d->t * a.Hq * a.tiles_w;
+    a.t_off = AF_STEM_PAD_T - d->pt; a.kt = d->kt;
+    AF_REQUIRE(a.tiles < (1LL << 31), "tstem_pool3: %lld tiles", a.tiles);
+    long long blocks = (a.tiles + 4 * 4 - 1) / (4 * 4);                   // ~4 tiles per wave
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    if (blocks < 1) blocks = 1;
+    hipStream_t s = (hipStream_t)stream;
+    if (d->dtype == AF_BF16) hipLaunchKernelGGL((tstem_pool3_kernel<AF_BF16>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((tstem_pool3_kernel<AF_F16>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+    AF_CHECK_LAUNCH("tstem_pool3_kernel");
     return AF_OK;
 }
 

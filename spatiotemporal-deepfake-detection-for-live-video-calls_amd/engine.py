@@ -373,10 +373,17 @@ class Engine:
         self.inputs = [("IN", (T, H, W), 1)]
         cur, nxt = "P0", "P1"
         d = _pool_out(spec.stem.out_dims(T, H, W), spec.stem.pool_after_bn)
-        plan.add(kind="tstem", cv=spec.stem, din=(T, H, W), dout=d, src="IN", dst=cur); plan.need(cur, d, spec.stem.cout)
         d2 = _pool_out(d, spec.stem_pool)
-        plan.add(kind="pool", pool=spec.stem_pool, ch=spec.stem.cout, din=d, dout=d2, src=cur, dst=nxt); plan.need(nxt, d2, spec.stem.cout)
-        cur, nxt, d = nxt, cur, d2
+        if (self.dtype != "f32" and os.environ.get("AF_FUSE_TSTEM_POOL", "1") == "1"
+                and _is_pool(spec.stem_pool, (1, 3, 3), (1, 2, 2), (0, 1, 1))):
+            # 16-bit: the stem's own 1x3x3 / stride-2 max-pool rides behind the temporal stem (the half-resolution tensor -
+            # 822 MB at 16 clips - is neither written nor read back)
+            plan.add(kind="tstem_pool3", cv=spec.stem, din=(T, H, W), dout=d, src="IN", dst=cur); plan.need(cur, d2, spec.stem.cout)
+            d = d2
+        else:
+            plan.add(kind="tstem", cv=spec.stem, din=(T, H, W), dout=d, src="IN", dst=cur); plan.need(cur, d, spec.stem.cout)
+            plan.add(kind="pool", pool=spec.stem_pool, ch=spec.stem.cout, din=d, dout=d2, src=cur, dst=nxt); plan.need(nxt, d2, spec.stem.cout)
+            cur, nxt, d = nxt, cur, d2
         fuse_tpool = _is_pool(spec.pool_after_s2, (2, 1, 1), (2, 1, 1), (0, 0, 0))
         c = spec.stem.cout
         for si, stage in enumerate(spec.stages):
@@ -490,10 +497,10 @@ class Engine:
             if kind == "tt_head":
                 self._materialise_tt_head(n_pack + k, e)
                 continue
-            if kind in ("stem", "stem_pool", "stem3_pool", "conv", "tstem"):
+            if kind in ("stem", "stem_pool", "stem3_pool", "conv", "tstem", "tstem_pool3"):
                 cv: ConvSpec = e["cv"]
                 op.kind = {"stem": _lib.AF_OP_STEM, "stem_pool": _lib.AF_OP_STEM_POOL, "stem3_pool": _lib.AF_OP_STEM3_POOL,
-                           "tstem": _lib.AF_OP_TSTEM}.get(kind, _lib.AF_OP_CONV)
+                           "tstem": _lib.AF_OP_TSTEM, "tstem_pool3": _lib.AF_OP_TSTEM_POOL3}.get(kind, _lib.AF_OP_CONV)
                 op.tag = TAG_STEM if kind != "conv" else _conv_tag(cv)
                 # a, b, stems and laterals carry their own ReLU; c (final_bn) takes the block's add + ReLU; the
                 # projection shortcut has neither (resnet_helper.py:311-326, 438-444; video_model_builder.py:136-143)
@@ -783,7 +790,7 @@ class Engine:
         """Output of op ``op_index`` as an (N,T,H,W,C) view of its buffer (valid until overwritten; ops that write
         into a wider, concatenated row return the full-width rows)."""
         op = self.ops[op_index]
-        if op.kind in (_lib.AF_OP_STEM_POOL, _lib.AF_OP_STEM3_POOL):
+        if op.kind in (_lib.AF_OP_STEM_POOL, _lib.AF_OP_STEM3_POOL, _lib.AF_OP_TSTEM_POOL3):
             shape = (op.conv.n, op.conv.to, (op.conv.ho - 1) // 2 + 1, (op.conv.wo - 1) // 2 + 1, op.conv.cout)
         elif op.kind == _lib.AF_OP_CONV_BC:
             shape = (op.conv2.n, op.conv2.to, op.conv2.ho, op.conv2.wo, op.out_ld or op.conv2.cout)

@@ -143,6 +143,53 @@ def test_temporal_stem_vs_oracle(dtype, dims, kt):
     assert err <= tol * (want[~nan].abs().max().item() + 1e-9), err
 
 
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+@pytest.mark.parametrize("dims,kt", [((1, 6, 20, 28), 5), ((2, 3, 16, 72), 5), ((1, 4, 10, 12), 3), ((1, 2, 14, 18), 1)])
+def test_temporal_stem_with_fused_stem_pool_vs_oracle(dtype, dims, kt):
+    """af_tstem_conv_bn_pool_relu_maxpool: the temporal stem with the stem's own MaxPool3d([1,3,3],[1,2,2],[0,1,1]) behind it in
+    one launch, against the oracle's stem followed by F.max_pool3d: odd half-resolution sizes (the window's last row / column
+    falls outside the map: clamped members), a ragged last tile, BN scales of both signs and a zero scale, a NaN pixel."""
+    import torch.nn.functional as F
+    n, t, h, w = dims
+    seed = 5151 + kt + w
+    lay = [("conv.weight", (64, 3, kt, 1, 1), "float32"), ("bn.0.weight", (64,), "float32"), ("bn.0.bias", (64,), "float32"),
+           ("bn.0.running_mean", (64,), "float32"), ("bn.0.running_var", (64,), "float32")]
+    sd = synth.fill_layout(lay, seed)
+    sd["conv.weight"] = sd["conv.weight"] * 3.0
+    sd["bn.0.weight"][1::2] *= -1.0
+    sd["bn.0.weight"][4] = 0.0
+    x = synth.synthetic_tensor((n, 3, t, h, w), seed)
+    x[0, 1, t // 2, 5, 7] = float("nan")
+    x = x.to(hh.TORCH_DT[dtype]).float()
+    sd["conv.weight"] = sd["conv.weight"].to(hh.TORCH_DT[dtype]).float()
+    half = oracle._conv_bn_pool_act(x.double(), sd["conv.weight"].double(), {k: v.double() for k, v in sd.items()}, "bn",
+                                    (kt // 2, 0, 0), True, True)
+    want = F.max_pool3d(half, (1, 3, 3), (1, 2, 2), (0, 1, 1))
+    L = hh.lib()
+    code = L.DTYPE_CODES[dtype]
+    stem_in = hh.pack_input_f32(x.cuda(), dtype)
+    scale, shift = hh.fold_bn(sd, "bn.0")
+    nbytes = L.lib.af_packed_tstem_weight_bytes(code)
+    packed = torch.empty(nbytes // 2, dtype=hh.TORCH_DT[dtype], device="cuda")
+    wsrc = sd["conv.weight"].float().cuda().contiguous()
+    L.check(L.lib.af_pack_tstem_weight(hh._p(wsrc), 64, kt, code, hh._p(packed), hh._stream()), "pack_tstem_weight")
+    d = L.ConvDesc()
+    d.n, d.t, d.h, d.w, d.cin, d.cout = n, t, h, w, 3, 64
+    d.kt, d.kh, d.kw, d.st, d.sh, d.sw, d.pt, d.ph, d.pw = kt, 1, 1, 1, 1, 1, kt // 2, 0, 0
+    d.to, d.ho, d.wo, d.relu, d.dtype = t, h // 2, w // 2, 1, code
+    hq, wq = (h // 2 - 1) // 2 + 1, (w // 2 - 1) // 2 + 1
+    assert tuple(want.shape[2:]) == (t, hq, wq)
+    out = torch.full((n, t, hq, wq, 64), 7.0, dtype=hh.TORCH_DT[dtype], device="cuda")
+    L.check(L.lib.af_tstem_conv_bn_pool_relu_maxpool(C.byref(d), hh._p(stem_in), hh._p(packed), hh._p(scale), hh._p(shift),
+                                                     hh._p(out), hh._stream()), "tstem_pool3")
+    got = hh.to_ncdhw(out).double()
+    tol = {"f16": 1.5e-3, "bf16": 1.2e-2}[dtype]
+    nan = torch.isnan(want)
+    assert nan.any() and not nan.all() and (torch.isnan(got) == nan).all()
+    err = (got - want)[~nan].abs().max().item()
+    assert err <= tol * (want[~nan].abs().max().item() + 1e-9), err
+
+
 def test_ftcn_plugin_surface_batch_and_hook(ftcn_weights, tmp_path):
     """ModelBase-style lifecycle of the FTCN-TT plugin; batch invariance; the last nn.Linear (mlp_head.1) is hookable
     like the reference's (feature.py:105-114)."""
