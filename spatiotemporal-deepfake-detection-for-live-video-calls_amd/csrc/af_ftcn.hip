@@ -194,6 +194,11 @@ __global__ __launch_bounds__(256) void tstem_kernel(const TStemArgs a) {
 // Lane = (final pixel frow of a 16-pixel tile, k-group fg = taps 2fg, 2fg+1); per window row three 16-byte loads per
 // tap chunk (two adjacent conv pixels each); the next row's loads (the next tile's first row behind the last one: six rows,
 // an even count, so the two register sets stay static) are issued before this row's 24 MFMAs.
+// Measured (B = 16 bf16): 0.39 + 0.23 ms for the two launches -> 0.53 ms.  The launch is bound by the vector ALU (max3 / min3 / NaN
+// flag per member and element, fragment assembly: ~1 300 operations next to 144 MFMAs per tile) AND by the vector-memory address
+// rate (36 loads per tile).  Tried and dropped: two 8-byte loads per member straight into the fragment registers (no assembly
+// moves, twice the load instructions: 0.63 ms); rows two per trip with static fragment sets + a wave-uniform skip of the min (or
+// max) when every BN scale has one sign (0.82 ms: the uniform conditions became branches inside the unrolled element loop).
 struct TStemP3Args {
     const char* in;
     const char* w;
