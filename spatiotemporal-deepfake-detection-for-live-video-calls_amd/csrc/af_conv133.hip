@@ -18,6 +18,7 @@
 // through an LDS output tile ([position][64 channels], swizzled like the patches): the workgroup stores whole 128-byte
 // rows, and does so under the MFMAs of the NEXT strip.
 #include "af_common.h"
+#include <stdlib.h>
 
 namespace af {
 
@@ -203,6 +204,154 @@ __global__ __launch_bounds__(256, 1) void conv133_c64_kernel(const C133Args a) {
     }
 }
 
+// Round 3: the same strip walk on EIGHT waves, two per SIMD: wave = (channel half ng = wave >> 2, m-tile group mg = wave & 3),
+// 32 output channels x 4 m-tiles each: 144 weight registers (9 taps x 2 k-halves x 2 channel tiles), 32 accumulators, two
+// fragment sets - ~210 VGPRs, so two waves fit a SIMD.  With one wave per SIMD every non-MFMA instruction of the strip (patch DMA
+// issue: 26 us per launch, tile stores: 16, epilogue: 14, of 145) sat in the MFMA stream's way; with two, one wave's DMA issue /
+// epilogue / stores run under the other's MFMAs.  The price: every B fragment is read by both channel halves (2x the LDS
+// fragment reads: ~125 B/clk of the CU's 256) and feeds 2 MFMAs instead of 4 - which is why the fragments of step s + 1 are read
+// a whole step (8 MFMAs) ahead of their use (round 1's 8-wave form read them right in front: a chain of LDS latencies, 58 %).
+template <int DT, int R>
+__global__ __launch_bounds__(512, 2) void conv133_c64x2_kernel(const C133Args a) {
+    typedef Elem<DT> E;
+    static_assert(E::EPC == 8, "16-bit operands only");
+    constexpr int MT = 4, NT2 = 2;
+    constexpr int OTROWS = 16 * 16;
+
+    extern __shared__ uint4 smem[];
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mg = wave & 3, ng = wave >> 2;
+    const int frow = lane & 15, fg = lane >> 4;
+    const int WP = a.W + 2;
+    const int NP = a.rows_alloc >> 3;
+    const int buf_bytes = a.rows_alloc * 128;
+    char* otile = reinterpret_cast<char*>(smem) + 2 * buf_bytes;
+
+    // ---- this wave's 32 output channels of the weights -> registers
+    // (taps 0-6 in registers: 112; the last two taps' fragments wait in LDS in fragment order - 144 + accumulators + fragments +
+    //  the store / DMA temporaries spilled 22 registers, and a scratch reload's vmcnt(0) also waits for the patch DMA in flight)
+    constexpr int RT = 7;                                        // taps whose weights live in registers
+    u32x4 wreg[RT][2][NT2];
+#pragma unroll
+    for (int tap = 0; tap < RT; ++tap)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < NT2; ++i) {
+                const int ch = ng * 32 + i * 16 + frow;
+                wreg[tap][kk][i] = *reinterpret_cast<const u32x4*>(a.w + ((ch * 9 + tap) * 64 + kk * 32 + fg * 8) * 2);
+                asm volatile("" : "+v"(wreg[tap][kk][i]));
+            }
+    float* bn_lds = reinterpret_cast<float*>(otile + OTROWS * 128);
+    if (tid < 64) { bn_lds[tid] = a.scale[tid]; bn_lds[64 + tid] = a.shift[tid]; }
+    uint4* w8 = reinterpret_cast<uint4*>(bn_lds + 128);          // taps RT .. 8: [tap][k-half][channel tile 0..3][64 lanes]
+    for (int idx = tid; idx < (9 - RT) * 512; idx += 512) {
+        const int f = idx >> 6, tap = RT + (f >> 3), kk = (f >> 2) & 1, ct = f & 3;
+        w8[idx] = *reinterpret_cast<const uint4*>(a.w + (((ct * 16 + frow) * 9 + tap) * 64 + kk * 32 + fg * 8) * 2);
+    }
+
+    unsigned* dma_tab = reinterpret_cast<unsigned*>(w8 + (9 - RT) * 512);
+    const int dma_row = lane >> 3, dma_chunk = (lane & 7) ^ dma_row;
+    for (int g = wave; g < NP; g += 8) {
+        const int q = g * 8 + dma_row - 1;
+        const int r = q / WP, c = q - r * WP;
+        const bool ok = q >= 0 && r < R + 2 && c >= 1 && c <= a.W;
+        dma_tab[g * 64 + lane] = ok ? ((unsigned)r << 24) | (unsigned)((r * a.W + (c - 1)) * 128 + dma_chunk * 16) : 0xffffffffu;
+    }
+    __syncthreads();
+    auto issue_patch = [&](int strip, int buf) {
+        const int frame = strip / a.strips_per_frame;
+        const int h0 = (strip - frame * a.strips_per_frame) * R;
+        const i32x4 desc = make_desc(a.in + ((long long)frame * a.H + h0 - 1) * a.W * 128);
+        for (int g = wave; g < NP; g += 8) {
+            const unsigned e = dma_tab[g * 64 + lane];
+            const bool ok = e != 0xffffffffu && (unsigned)(h0 - 1 + (int)(e >> 24)) < (unsigned)a.H;
+            blds16(ok ? (e & 0xffffffu) : kOutOfRange, desc, 0, __builtin_amdgcn_readfirstlane(lds0 + buf * buf_bytes + g * 1024));
+        }
+    };
+    const int G = gridDim.x, b = blockIdx.x;
+    const int s0 = (int)((long long)a.total_strips * b / G), s1 = (int)((long long)a.total_strips * (b + 1) / G);
+    if (s0 < s1) issue_patch(s0, 0);
+    auto store_tile = [&](int sp) {
+        const int frame = sp / a.strips_per_frame;
+        const int h0 = (sp - frame * a.strips_per_frame) * R;
+        char* obase = a.out + ((long long)frame * a.H + h0) * a.W * 128;
+#pragma unroll
+        for (int j = 0; j < OTROWS * 8 / 512; ++j) {
+            const int row = (tid + 512 * j) >> 3, chunk = tid & 7, r = row / WP, c = row - r * WP;
+            if (r < R && c >= 1 && c <= a.W && h0 + r < a.H) {            // halo columns / rows beyond the strip are not stored
+                const u32x4 o = *reinterpret_cast<const u32x4*>(otile + row * 128 + ((chunk ^ (row & 7)) << 4));
+                __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(obase + (r * a.W + (c - 1)) * 128 + chunk * 16));
+            }
+        }
+    };
+
+    for (int s = s0; s < s1; ++s) {
+        const int buf = (s - s0) & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (s + 1 < s1) issue_patch(s + 1, buf ^ 1);
+
+        const char* xb = reinterpret_cast<const char*>(smem) + buf * buf_bytes;
+        f32x4 acc[NT2][MT];
+#pragma unroll
+        for (int i = 0; i < NT2; ++i)
+#pragma unroll
+            for (int k = 0; k < MT; ++k) acc[i][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // ONE fragment set, refilled in place: m-tile k's fragment of step s + 1 is read right behind the two MFMAs that consumed
+        // its fragment of step s - still a whole step (8 MFMAs of this wave) ahead of its use, with half the registers of two
+        // sets (two sets + 144 weight registers spilled)
+        uint4 bf[MT];
+        auto read_frag = [&](int step, int k) {
+            const int tap = step >> 1, kk = step & 1;
+            const int row = frow + (tap / 3) * WP + (tap % 3);
+            return *reinterpret_cast<const uint4*>(xb + row * 128 + (((kk * 4 + fg) ^ (row & 7)) << 4) + (mg + 4 * k) * (16 * 128));
+        };
+#pragma unroll
+        for (int k = 0; k < MT; ++k) bf[k] = read_frag(0, k);
+#pragma unroll
+        for (int step = 0; step < 18; ++step) {
+            if (step == 6 && s > s0) store_tile(s - 1);
+#pragma unroll
+            for (int k = 0; k < MT; ++k) {
+#pragma unroll
+                for (int i = 0; i < NT2; ++i)
+                    Mma<DT>::run(step < 2 * RT ? __builtin_bit_cast(uint4, wreg[step < 2 * RT ? step >> 1 : 0][step & 1][i])
+                                               : w8[(((step >> 1) - RT) * 8 + (step & 1) * 4 + ng * 2 + i) * 64 + lane],
+                                 bf[k], acc[i][k]);
+                if (step + 1 < 18) bf[k] = read_frag(step + 1, k);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        f32x4 sc[NT2], sf[NT2];
+#pragma unroll
+        for (int i = 0; i < NT2; ++i) {
+            sc[i] = *reinterpret_cast<const f32x4*>(bn_lds + ng * 32 + i * 16 + fg * 4);
+            sf[i] = *reinterpret_cast<const f32x4*>(bn_lds + 64 + ng * 32 + i * 16 + fg * 4);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int k = 0; k < MT; ++k) {
+            const int row = (mg + 4 * k) * 16 + frow;
+#pragma unroll
+            for (int i = 0; i < NT2; ++i) {
+                f32x4 v = acc[i][k] * sc[i] + sf[i];
+                v[0] = relu_f(v[0]); v[1] = relu_f(v[1]); v[2] = relu_f(v[2]); v[3] = relu_f(v[3]);
+                const int ch = ng * 32 + i * 16 + fg * 4;
+                Vec4<DT>::store(otile + row * 128 + (((ch >> 3) ^ (row & 7)) << 4) + (ch & 4) * 2, v);
+            }
+        }
+    }
+    if (s0 < s1) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        store_tile(s1 - 1);
+    }
+}
+
 template <int DT>
 static int launch_c133(C133Args& a, hipStream_t stream) {
     constexpr int R = 4;
@@ -211,10 +360,17 @@ static int launch_c133(C133Args& a, hipStream_t stream) {
     a.strips_per_frame = (a.H + R - 1) / R;
     a.total_strips = a.frames * a.strips_per_frame;
     a.rows_alloc = (((R + 2) * WP + 2 + 16) + 7) & ~7;
-    const int lds = 2 * a.rows_alloc * 128 + 16 * 16 * 128 + 128 * 4 + (a.rows_alloc / 8) * 64 * 4;
+    const int lds = 2 * a.rows_alloc * 128 + 16 * 16 * 128 + 128 * 4 + 2 * 512 * 16 + (a.rows_alloc / 8) * 64 * 4;   // (+ the last two taps' fragments: 8-wave form)
     const int grid = a.total_strips < g_num_cus ? a.total_strips : g_num_cus;
-    AF_SET_MAX_LDS((&conv133_c64_kernel<DT, R>), 160 * 1024, "conv133");
-    hipLaunchKernelGGL((conv133_c64_kernel<DT, R>), dim3(grid), dim3(256), lds, stream, a);
+    // AF_C64_WAVES=4: the round-1 / 2 form (one wave per SIMD, all 64 channels per wave) for A/B runs
+    const char* ew = getenv("AF_C64_WAVES");
+    if (ew && atoi(ew) == 4) {
+        AF_SET_MAX_LDS((&conv133_c64_kernel<DT, R>), 160 * 1024, "conv133");
+        hipLaunchKernelGGL((conv133_c64_kernel<DT, R>), dim3(grid), dim3(256), lds, stream, a);
+    } else {
+        AF_SET_MAX_LDS((&conv133_c64x2_kernel<DT, R>), 160 * 1024, "conv133");
+        hipLaunchKernelGGL((conv133_c64x2_kernel<DT, R>), dim3(grid), dim3(512), lds, stream, a);
+    }
     AF_CHECK_LAUNCH("conv133_c64_kernel");
     return AF_OK;
 }
