@@ -255,6 +255,77 @@ class FasterCropAlignXRay:
                                                        size, C.c_void_p(out[lo:hi].data_ptr()), stream), "warp_affine_clip_u8")
 
 
+class StreamingCropAligner:
+    """The same alignment for a LIVE track (reference test/af_realtime.py:RealtimeAF.step, test/app_realtime.py:153: one call per
+    captured frame; every `stride` frames the last `clip_size` crops of the track are aligned and classified).  The reference
+    keeps the crops in a host deque and hands all 32 to FasterCropAlignXRay when the window closes - ~17 MB to stage and upload
+    on the critical path of every window.  Here a crop goes to the GPU when its frame is captured (`push`: one copy into a pinned
+    slot + one asynchronous H2D per frame, ~0.5 MB), so that closing a window (`align_last`) costs the similarity fit over the
+    window's landmarks and ONE warp launch over crops that are already resident: enqueue -> score is fit + warp + forward.
+    Same arithmetic as FasterCropAlignXRay (its fit, the same kernel): `align_last(n)` equals
+    `FasterCropAlignXRay(size)(infos[-n:], crops[-n:])`."""
+
+    def __init__(self, size: int = 224, capacity: int = 64, max_crop_pixels: int = 512 * 512, device: Optional[torch.device] = None):
+        self.aligner = FasterCropAlignXRay(size, device=device)
+        self.capacity = int(capacity)
+        self.slot_bytes = (max_crop_pixels * 3 + 15) // 16 * 16
+        dev = torch.device(device or torch.device("cuda", torch.cuda.current_device()))
+        if dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        self.device = dev
+        self.host = torch.empty(self.capacity * self.slot_bytes, dtype=torch.uint8, pin_memory=True)
+        self.dev = torch.empty(self.capacity * self.slot_bytes, dtype=torch.uint8, device=dev)
+        self._hv = self.host.numpy()
+        self.frames = []                   # (info, crop shape, slot) of the frames still resident, oldest first
+        self.count = 0
+
+    def push(self, info, crop: np.ndarray) -> None:
+        """a captured frame of the track: landmark record ``(_, ldm5, ldm68, box)`` + its HxWx3 uint8 crop"""
+        if not (isinstance(crop, np.ndarray) and crop.dtype == np.uint8 and crop.ndim == 3 and crop.shape[2] == 3):
+            raise AssertionError("aligner: images must be HxWx3 uint8 numpy arrays")
+        if crop.size > self.slot_bytes:
+            raise ValueError("aligner: a %dx%d crop exceeds the slot size (max_crop_pixels)" % (crop.shape[1], crop.shape[0]))
+        slot = self.count % self.capacity
+        self.count += 1
+        lo = slot * self.slot_bytes
+        np.copyto(self._hv[lo:lo + crop.size], crop.reshape(-1) if crop.flags.c_contiguous else np.ascontiguousarray(crop).reshape(-1))
+        with torch.cuda.device(self.device):
+            # (stream order protects the slot: the warp launches that read its previous occupant were enqueued earlier on this
+            #  stream; the pinned slot itself was last read by the H2D of `capacity` frames ago, long complete)
+            self.dev[lo:lo + crop.size].copy_(self.host[lo:lo + crop.size], non_blocking=True)
+        self.frames.append((tuple(info[:4]), crop.shape, slot))
+        if len(self.frames) > self.capacity - 1:
+            self.frames.pop(0)
+
+    def align_last(self, n: int = 32, out: Optional[torch.Tensor] = None):
+        """(landmarks68 (n,68,2), aligned clip (n, size, size, 3) uint8 CUDA tensor) of the last n pushed frames; ``out``: write
+        the clip there (e.g. the static input of a graph-replayed forward) instead of a new tensor"""
+        if n > len(self.frames):
+            raise ValueError("aligner: %d frames requested, %d resident" % (n, len(self.frames)))
+        win = self.frames[-n:]
+        al = self.aligner
+        boxes = np.array([f[0][3] for f in win])
+        five = np.array([f[0][1] for f in win])
+        l68 = np.array([f[0][2] for f in win])
+        left_top = boxes[:, :2].min(0)
+        w, h = boxes[:, 2:].max(0) - left_top
+        diff = boxes[:, :2] - left_top[None]
+        tfm, trans = estimate_batch_transform(five + diff[:, None, :], al.std_points)
+        t68 = _apply(trans, l68 + diff[:, None, :])
+        if out is None:
+            out = torch.empty((n, al.image_size, al.image_size, 3), dtype=torch.uint8, device=self.device)
+        elif out.shape != (n, al.image_size, al.image_size, 3) or out.dtype != torch.uint8 or not out.is_contiguous() or out.device != self.device:
+            raise ValueError("aligner: `out` must be a contiguous uint8 (%d,%d,%d,3) tensor on %s" % (n, al.image_size, al.image_size, self.device))
+        shapes = [f[1] for f in win]
+        for i, shp in enumerate(shapes):
+            x, y = int(diff[i][0]), int(diff[i][1])
+            if x < 0 or y < 0 or x + shp[1] > int(w) or y + shp[0] > int(h):
+                raise ValueError("aligner: frame %d (%dx%d at %d,%d) does not fit the %dx%d canvas" % (i, shp[1], shp[0], x, y, int(w), int(h)))
+        with torch.cuda.device(self.device):
+            al.launch_warps(self.dev, [f[2] * self.slot_bytes for f in win], shapes, diff, int(h), int(w), tfm, out)
+        return t68, out
+
+
 def synthetic_clip(frames: int = 32, seed: int = 0, mirrored: bool = False):
     """(infos, crops) of a synthetic tracked face for tests / the bench: 5 points = the standard points under a random
     similarity + per-frame jitter, tracker boxes of slightly different origin and size per frame, random-noise crops."""

@@ -269,6 +269,37 @@ class I3D8x8(_HipNetwork):
         return s.float().cpu().numpy() if as_numpy else s
 
 
+class LiveScorer:
+    """One tracked face of a live call: ``score = scorer(aligned_clip_u8)`` = ``ClassifierSvc.infer_scores`` for a single window
+    (test/af_realtime.py:75-96), with the ~50 launches of the B = 1 forward recorded ONCE into a HIP graph and replayed per window:
+    after a second of idle between windows the host side runs cold and issuing those launches one by one (0.5 - 0.9 ms) was on the
+    critical path of enqueue -> score; a replay is one call.  ``scorer.clip`` is the static (1, T, H, W, 3) uint8 input - the
+    aligner can write the window straight into it (``StreamingCropAligner.align_last(n, out=scorer.clip[0])``) - and the returned
+    scores are those of ``infer_scores`` bit for bit (same kernels, same order)."""
+
+    def __init__(self, network: "I3D8x8", clip_size: int = 32, crop: int = 224):
+        self.network = network
+        dev = next(network.parameters()).device
+        self.clip = torch.zeros((1, clip_size, crop, crop, 3), dtype=torch.uint8, device=dev)
+        with torch.inference_mode(), torch.cuda.device(dev):
+            for _ in range(2):                                          # engine construction, weight packing, kernel attributes
+                network.forward_clips_u8(self.clip, return_scores=True)
+            torch.cuda.synchronize(dev)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self._scores = network.forward_clips_u8(self.clip, return_scores=True)["scores"]
+        self._host = torch.empty(self._scores.shape, dtype=torch.float32, pin_memory=True)
+
+    def __call__(self, aligned_clip_u8: Optional[torch.Tensor] = None):
+        """aligned_clip_u8: (T,H,W,3) or (1,T,H,W,3) uint8 device tensor, or None when the window was written into ``self.clip``"""
+        if aligned_clip_u8 is not None:
+            self.clip.copy_(aligned_clip_u8.reshape(self.clip.shape), non_blocking=True)
+        self.graph.replay()
+        self._host.copy_(self._scores.float(), non_blocking=True)
+        torch.cuda.current_stream(self.clip.device).synchronize()
+        return self._host.numpy().copy()
+
+
 class SlowFast8x8(_HipNetwork):
     """Two-pathway SlowFast-R50 (reference slowfast/models/video_model_builder.py:146-387) on the same kernels:
     the Fast->Slow laterals (FuseFastToSlow, :86-143) are strided temporal convs that write their channels straight

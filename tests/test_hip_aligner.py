@@ -103,3 +103,23 @@ def test_aligner_feeds_classifier_without_host_round_trip(weights0):
         y_host = clf(synth.normalize_like_callers(clip_dev.cpu()[None]).cuda())["final_output"]
     assert y_dev.shape == (1, 1) and torch.isfinite(y_dev).all()
     assert abs(float(y_dev) - float(y_host)) <= 2e-4
+
+
+def test_streaming_aligner_equals_the_batch_call():
+    """StreamingCropAligner: crops pushed frame by frame (incl. more frames than a window and a wrap of its slot ring),
+    align_last(n) == FasterCropAlignXRay on the last n frames - same fit, same kernel: bit-exact, landmarks identical."""
+    g = load_npz("f8_aligner.npz")
+    rng = np.random.default_rng(5)
+    infos, images = _clip(rng, g, "t32_224")
+    sal = aligner.StreamingCropAligner(224, capacity=12, max_crop_pixels=max(im.shape[0] * im.shape[1] for im in images))
+    ref = aligner.FasterCropAlignXRay(224)
+    for i, (info, im) in enumerate(zip(infos, images)):
+        sal.push(info, im)
+        if i in (7, 20, 31):                                     # before and after the 12-slot ring wrapped
+            n = 8
+            got68, got = sal.align_last(n)
+            want68, want = ref(infos[i + 1 - n:i + 1], images[i + 1 - n:i + 1])
+            np.testing.assert_allclose(got68, want68, rtol=0, atol=0)
+            assert (got.cpu().numpy() == want).all()
+    with pytest.raises(ValueError):
+        sal.align_last(12)                                       # only capacity - 1 frames stay resident

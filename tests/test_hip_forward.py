@@ -465,3 +465,21 @@ def test_bench_two_rank_rehearsal_shards_the_real_forward():
     want = torch.cat([ya, yb])
     got = torch.tensor(line["gathered_logits"])
     assert got.shape == want.shape and torch.equal(got, want), (got, want)
+
+
+def test_live_scorer_graph_replay_equals_infer_scores():
+    """LiveScorer: the B = 1 forward recorded once into a HIP graph and replayed per window gives infer_scores' value bit for bit,
+    for a clip passed in and for one written into its static input (as the streaming aligner does), several windows in a row."""
+    from af_mi355x.classifier import LiveScorer
+    clf = Classifier(precision="f16")
+    clf.network.load_state_dict(synth.synthetic_state_dict(seed=0))
+    clf = clf.cuda().eval()
+    scorer = LiveScorer(clf.network)
+    with torch.inference_mode():
+        for seed in (1, 2, 3):
+            u8 = synth.synthetic_clips_u8(1, seed=seed, kind="smooth").cuda()
+            want = clf.network.infer_scores(u8)
+            got = scorer(u8[0])
+            assert got.shape == want.shape and float(got[0]) == float(want[0]), (got, want)
+            scorer.clip.copy_(u8)
+            assert float(scorer()[0]) == float(want[0])
