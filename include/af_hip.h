@@ -146,6 +146,10 @@ int64_t af_packed_stem_weight_bytes_rgb3(int kt, int dtype);
 int af_pack_stem_weight_rgb3(const float* w_oidhw, int cout, int kt, int dtype, void* packed, void* stream);
 int af_stem_conv_bn_relu_maxpool_rgb3(const af_conv_desc* d, const void* stem_in, const void* w_packed,
                                       const float* scale, const float* shift, void* out, void* stream);
+/* the same with a pooled row stride of out_ld channels (>= 64): SlowFast's Slow stem writes its 64 channels in front of the
+ * lateral's (FuseFastToSlow concatenates by channel, video_model_builder.py:136-143) (ABI 3) */
+int af_stem_conv_bn_relu_maxpool_rgb3_ld(const af_conv_desc* d, const void* stem_in, const void* w_packed, const float* scale,
+                                         const float* shift, void* out, int out_ld, void* stream);
 
 /* Conv3d(bias=False)+BN[+residual add][+ReLU] as one implicit-GEMM launch: the a/b/c convs of
  * BottleneckTransform (resnet_helper.py:267-325), the projection shortcut and the add+ReLU of

@@ -80,6 +80,7 @@ ABI = {
     "af_packed_stem_weight_bytes_rgb3": (C.c_int64, [C.c_int] * 2),
     "af_pack_stem_weight_rgb3": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "af_stem_conv_bn_relu_maxpool_rgb3": (C.c_int, [C.POINTER(ConvDesc)] + [C.c_void_p] * 6),
+    "af_stem_conv_bn_relu_maxpool_rgb3_ld": (C.c_int, [C.POINTER(ConvDesc)] + [C.c_void_p] * 5 + [C.c_int, C.c_void_p]),
     "af_conv_workspace_bytes": (C.c_int64, [C.POINTER(ConvDesc)]),
     "af_conv3d_bn_act": (C.c_int, [C.POINTER(ConvDesc)] + [C.c_void_p] * 6 + [C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
     "af_conv3d_dual_bn_act": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_void_p, C.POINTER(ConvDesc)] + [C.c_void_p] * 5

@@ -66,7 +66,7 @@ static int run_one(const af_op& op, hipStream_t s) {
             return af_pack_input_u8((const uint8_t*)op.in, op.conv.n, op.conv.t, op.conv.h, op.conv.w, op.mean, op.std_,
                                     op.conv.dtype, op.out, s);
         case AF_OP_STEM3_POOL:
-            return af_stem_conv_bn_relu_maxpool_rgb3(&op.conv, op.in, op.weight, op.scale, op.shift, op.out, s);
+            return af_stem_conv_bn_relu_maxpool_rgb3_ld(&op.conv, op.in, op.weight, op.scale, op.shift, op.out, op.out_ld, s);
         case AF_OP_PACK3_F32:
             return af_pack_input_f32_rgb3((const float*)op.in, op.conv.n, op.conv.t, op.conv.h, op.conv.w, op.in_strides[0],
                                           op.in_strides[1], op.in_strides[2], op.in_strides[3], op.in_strides[4],

@@ -31,6 +31,7 @@ struct Stem3Args {
     int Hq, Wq;          // pooled dims
     int frames;          // N*To
     int bands, band_rows;
+    int out_ld;          // pooled row stride in channels (>= 64: room for a lateral's channels behind them)
 };
 
 // PW: the image is at most 7 column tiles wide (224 x 224: 112 columns), so wave 7 has no MFMA work - it becomes the
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(512, 2) void stem3_pool_kernel(const Stem3Args a) {
                 elem_t* oe = reinterpret_cast<elem_t*>(&o);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) oe[e] = E::from_f32(m[e]);
-                *reinterpret_cast<uint4*>(a.out + ((((long long)n * a.To + to) * a.Hq + j) * a.Wq + q) * (COUT * 2) + ch * 2) = o;
+                *reinterpret_cast<uint4*>(a.out + ((((long long)n * a.To + to) * a.Hq + j) * a.Wq + q) * (a.out_ld * 2) + ch * 2) = o;
             }
         };
 
@@ -372,8 +373,16 @@ extern "C" int af_pack_stem_weight_rgb3(const float* w, int cout, int kt, int dt
     return AF_OK;
 }
 
+extern "C" int af_stem_conv_bn_relu_maxpool_rgb3_ld(const af_conv_desc* d, const void* stem_in, const void* w_packed,
+                                                    const float* scale, const float* shift, void* out, int out_ld, void* stream);
+
 extern "C" int af_stem_conv_bn_relu_maxpool_rgb3(const af_conv_desc* d, const void* stem_in, const void* w_packed,
                                                  const float* scale, const float* shift, void* out, void* stream) {
+    return af_stem_conv_bn_relu_maxpool_rgb3_ld(d, stem_in, w_packed, scale, shift, out, 0, stream);
+}
+
+extern "C" int af_stem_conv_bn_relu_maxpool_rgb3_ld(const af_conv_desc* d, const void* stem_in, const void* w_packed,
+                                                    const float* scale, const float* shift, void* out, int out_ld, void* stream) {
     AF_REQUIRE(d && stem_in && w_packed && scale && shift && out, "stem3_pool: null argument");
     AF_REQUIRE(d->dtype == AF_BF16 || d->dtype == AF_F16, "stem3_pool: 16-bit dtypes only");
     AF_REQUIRE(d->cin == 3 && d->cout == 64, "stem3_pool: expects 3 -> 64 channels");
@@ -393,6 +402,9 @@ extern "C" int af_stem_conv_bn_relu_maxpool_rgb3(const af_conv_desc* d, const vo
     a.kt = d->kt; a.To = to; a.Ho = ho; a.Wo = wo;
     a.Hq = (ho - 1) / 2 + 1; a.Wq = (wo - 1) / 2 + 1;
     a.frames = d->n * to;
+    if (out_ld == 0) out_ld = 64;
+    AF_REQUIRE(out_ld >= 64 && out_ld % 8 == 0, "stem3_pool: bad out_ld %d", out_ld);
+    a.out_ld = out_ld;
     {
         const int cus = device_cus();
         int bands = a.frames >= cus ? 1 : cus / a.frames;

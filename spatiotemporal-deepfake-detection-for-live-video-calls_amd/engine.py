@@ -97,7 +97,7 @@ class PackedWeights:
                 check(lib.af_pack_conv_weight(_ptr(w), cv.cout, cv.cin, kt, kh, kw, code, _ptr(packed), st),
                       "af_pack_conv_weight")
             self.w[cv.conv], self.scale[cv.conv], self.shift[cv.conv] = packed, scale, shift
-            if (cv.conv in stems and not isinstance(spec, (FtcnTTSpec, SlowFastSpec)) and dtype != "f32" and cv.cout == 64
+            if (cv.conv in stems and not isinstance(spec, FtcnTTSpec) and dtype != "f32" and cv.cout == 64
                     and (kh, kw) == (7, 7)):
                 # the K-packed image of the same stem weights for the fused 16-bit stem (3 real channels, af_stem3.hip)
                 nb3 = lib.af_packed_stem_weight_bytes_rgb3(kt, code)
@@ -409,8 +409,16 @@ class Engine:
         ds = spec.stems[0].out_dims(Ts, H, W); ds2 = _pool_out(ds, spec.stem_pool)
         df = spec.stems[1].out_dims(T, H, W); df2 = _pool_out(df, spec.stem_pool)
         ld0 = spec.stems[0].cout + fuse_w[0]
-        plan.add(kind="stem", cv=spec.stems[0], din=(Ts, H, W), dout=ds, src="IN_S", dst="S1"); plan.need("S1", ds, spec.stems[0].cout)
-        plan.add(kind="pool", pool=spec.stem_pool, ch=spec.stems[0].cout, din=ds, dout=ds2, src="S1", dst="S0", ld=ld0)
+        self.rgb3_inputs = set()
+        if (spec.stems[0].conv in getattr(self.weights, "w3", {}) and os.environ.get("AF_SLOWFAST_STEM3", "1") == "1"
+                and _is_pool(spec.stem_pool, (1, 3, 3), (1, 2, 2), (0, 1, 1)) and ds[2] <= 128):
+            # 16-bit: the Slow stem + its max-pool as the K-packed fused stem (3-channel input layout), pooled rows at the widened stride
+            self.rgb3_inputs.add("IN_S")
+            plan.add(kind="stem3_pool", cv=spec.stems[0], din=(Ts, H, W), dout=ds, src="IN_S", dst="S0", ld=ld0)
+            plan.need("S1", ds2, spec.stems[0].cout)
+        else:
+            plan.add(kind="stem", cv=spec.stems[0], din=(Ts, H, W), dout=ds, src="IN_S", dst="S1"); plan.need("S1", ds, spec.stems[0].cout)
+            plan.add(kind="pool", pool=spec.stem_pool, ch=spec.stems[0].cout, din=ds, dout=ds2, src="S1", dst="S0", ld=ld0)
         plan.need("S0", ds2, ld0)
         plan.add(kind="stem", cv=spec.stems[1], din=(T, H, W), dout=df, src="IN_F", dst="F1"); plan.need("F1", df, spec.stems[1].cout)
         plan.add(kind="pool", pool=spec.stem_pool, ch=spec.stems[1].cout, din=df, dout=df2, src="F1", dst="F0")
@@ -450,10 +458,12 @@ class Engine:
         es = 4 if self.dtype == "f32" else 2
         self.buf = {k: torch.empty(max(v, 8), dtype=tdt, device=device) for k, v in plan.sizes.items()}
         self.rgb3 = getattr(self, "rgb3", False)
-        self.k_pack_f32 = _lib.AF_OP_PACK3_F32 if self.rgb3 else _lib.AF_OP_PACK_F32
+        # inputs that feed a K-packed stem take the 3-channel layout (the single input of the i3d engine; SlowFast: the Slow one)
+        r3 = set(getattr(self, "rgb3_inputs", ())) | ({self.inputs[0][0]} if self.rgb3 else set())
+        self.k_pack_f32 = [_lib.AF_OP_PACK3_F32 if name in r3 else _lib.AF_OP_PACK_F32 for name, _, _ in self.inputs]
         self.k_pack_u8 = _lib.AF_OP_PACK3_U8 if self.rgb3 else _lib.AF_OP_PACK_U8
         for name, dims, _ in self.inputs:                           # padded stem inputs: halos stay zero forever
-            nbytes = (lib.af_stem_input_bytes_rgb3 if self.rgb3 else lib.af_stem_input_bytes)(batch, dims[0], dims[1], dims[2], self.code)
+            nbytes = (lib.af_stem_input_bytes_rgb3 if name in r3 else lib.af_stem_input_bytes)(batch, dims[0], dims[1], dims[2], self.code)
             self.buf[name] = torch.zeros(nbytes // es, dtype=tdt, device=device)
         self.head_positions = self.head_dims[0] * self.head_dims[1] * self.head_dims[2]
         self.pooled = torch.empty((batch, self.head_positions, self.head_width), dtype=torch.float32, device=device)
@@ -470,7 +480,7 @@ class Engine:
         self.op_dst: List[Optional[str]] = [name for name, _, _ in self.inputs] + [e.get("dst") for e in plan.entries]
         for i, (name, dims, _) in enumerate(self.inputs):
             pk = self.ops[i]
-            pk.kind, pk.tag = self.k_pack_f32, TAG_PACK
+            pk.kind, pk.tag = self.k_pack_f32[i], TAG_PACK
             pk.conv.n, (pk.conv.t, pk.conv.h, pk.conv.w), pk.conv.dtype = batch, dims, self.code
             pk.out = self.buf[name].data_ptr()
             self.op_names.append("input_pack" if n_pack == 1 else "input_pack_" + name)
@@ -736,7 +746,7 @@ class Engine:
         if x.dtype != torch.float32 or not x.is_cuda:
             raise ValueError("inputs must be fp32 HIP tensors")
         pk = self.ops[i]
-        pk.kind = self.k_pack_f32
+        pk.kind = self.k_pack_f32[i]
         pk.in_ = x.data_ptr()
         st = list(x.stride())
         st[2] *= tstride
