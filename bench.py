@@ -118,6 +118,11 @@ def roofline_report(eng, args, line, reps=5):
             side = op.conv3.cin if op.in3 else cc_.cout
             eng_bytes[i] = es * (pos * (cc_.cin + side + cc_.cout + ca.cout) + cc_.cout * (cc_.cin + (op.conv3.cin if op.in3 else 0))
                                  + ca.cout * ca.cin * 3)
+        elif op.kind == _lib.AF_OP_CONV_CPA:             # b tile + residual in; pooled trunk (whole or 1 position in 4) + a out
+            cc_, ca = op.conv, op.conv2
+            pos, posp = cc_.n * cc_.to * cc_.ho * cc_.wo, ca.n * ca.to * ca.ho * ca.wo
+            eng_bytes[i] = es * (pos * (cc_.cin + cc_.cout) + posp * cc_.cout // (op.x_sub * op.x_sub) + posp * ca.cout
+                                 + cc_.cout * cc_.cin + ca.cout * ca.cin * 3)
         elif op.kind == _lib.AF_OP_BLOCK_ABC:            # trunk in + trunk out + the three weights; a and b stay on chip
             ca, cb, cc_ = op.conv, op.conv2, op.conv3
             pos = ca.n * ca.t * ca.h * ca.w
@@ -155,6 +160,8 @@ def roofline_report(eng, args, line, reps=5):
             kname = _lib.lib.af_conv_variant_name(_lib.lib.af_conv_variant(C.byref(op.conv), d2)).decode()
         elif op.kind == _lib.AF_OP_CONV_CA:
             kname = "conv_ca<c(i) -> a(i+1) fused>"
+        elif op.kind == _lib.AF_OP_CONV_CPA:
+            kname = "conv_cpa<c + temporal pool -> a of the next stage>"
         elif op.kind == _lib.AF_OP_CONV_BC:
             kname = "conv133g<b + c fused>"
         elif op.kind == _lib.AF_OP_BLOCK_ABC:

@@ -220,6 +220,20 @@ int af_conv3d_ca_bn_act(const af_conv_desc* dc, const void* in_b, const void* wc
                         const af_conv_desc* da, const void* wa_packed, const float* scale_a, const float* shift_a, void* out_a,
                         void* stream);
 
+/* The s2 -> s3 boundary as ONE launch (16-bit): the c conv of s2's last block with its residual and ReLU, pathway0_pool
+ * (MaxPool3d [2,1,1], video_model_builder.py:566-569) and the 3x1x1 a conv of s3's block 0 (resnet_helper.py:267-281):
+ *     x     = relu( bn_c(conv1x1x1_c(b)) + residual )                   [n][32][h][w][C]  (never stored)
+ *     xp    = max(x[2t'], x[2t'+1])                                     -> out_x
+ *     a_out = relu( bn_a(conv3x1x1_a(xp)) )                             -> out_a [n][16][h][w][128]
+ * dc: 64 -> C (C % 64 == 0, C <= 256), tpool = 1, t = 32, h even, w % 4 == 0; da: C -> 128, kernel [3,1,1], pad [1,0,0], t = 16.
+ * x_sub = 1: out_x is the whole pooled trunk [n][16][h][w][C]; x_sub = 2: only its even (h, w) positions, packed as
+ * [n][16][h/2][w/2][C] - all that a 1x1x1 convolution of stride (1,2,2) (the stage's projection shortcut, resnet_helper.py:
+ * 411-431) reads; its caller then runs that convolution with stride 1 over the packed tensor.  (ABI 3) */
+int af_conv_cpa_fusable(const af_conv_desc* dc, const af_conv_desc* da, int x_sub);
+int af_conv3d_cpa_bn_act(const af_conv_desc* dc, const void* in_b, const void* wc_packed, const float* scale_c, const float* shift_c,
+                         const void* residual, void* out_x, int x_sub, const af_conv_desc* da, const void* wa_packed,
+                         const float* scale_a, const float* shift_a, void* out_a, void* stream);
+
 /* which tile variant af_conv3d_[dual_]bn_act launches for `d` (+ optional `d2`) (>= 0) and its kernel name:
  * lets a profiler attribute per-layer device time and FLOPs to a kernel instantiation (bench.py roofline). */
 int af_conv_variant(const af_conv_desc* d, const af_conv_desc* d2);
@@ -356,7 +370,10 @@ enum af_op_kind { AF_OP_STEM = 0, AF_OP_CONV = 1, AF_OP_MAXPOOL = 2, AF_OP_HEAD 
                      pool is unused, in2 == in and (conv4, weight4) = the shortcut conv (af_block_abc_bn_act) */
                   AF_OP_BLOCK_ABC = 20,
                   /* TSTEM with the stem's 1x3x3 / stride-2 max-pool fused behind it (af_tstem_conv_bn_pool_relu_maxpool) */
-                  AF_OP_TSTEM_POOL3 = 21 };
+                  AF_OP_TSTEM_POOL3 = 21,
+                  /* c of s2's last block + temporal pool + a of s3's block 0: fields as CONV_CA (no conv3 segment), x_sub
+                     (af_conv3d_cpa_bn_act) */
+                  AF_OP_CONV_CPA = 22 };
 
 typedef struct af_op {
     int32_t kind;                    /* af_op_kind */
@@ -396,6 +413,9 @@ typedef struct af_op {
     const float* shift3;
     af_conv_desc conv4;
     const void* weight4;
+    /* CONV_CPA: 1 = the whole pooled trunk is stored, 2 = its even (h, w) positions, packed (ABI 3) */
+    int32_t x_sub;
+    int32_t reserved0;
 } af_op;
 
 /* Enqueue ops[0..n) in order on `stream` (AltFreezing: ResNet.forward, video_model_builder.py:561-578). */

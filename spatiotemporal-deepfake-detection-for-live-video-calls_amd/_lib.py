@@ -9,7 +9,7 @@ LIB_PATH = os.environ.get("AF_HIP_LIB") or os.path.join(HERE, "libafhip.so")   #
 AF_F32, AF_BF16, AF_F16 = 0, 1, 2
 (AF_OP_STEM, AF_OP_CONV, AF_OP_MAXPOOL, AF_OP_HEAD, AF_OP_PACK_F32, AF_OP_PACK_U8, AF_OP_CONV_DUAL, AF_OP_STEM_POOL, AF_OP_AVGPOOL,
  AF_OP_LINEAR, AF_OP_TSTEM, AF_OP_TOKENS, AF_OP_LAYERNORM, AF_OP_ATTENTION, AF_OP_GELU, AF_OP_CONV_BC, AF_OP_PACK3_F32,
- AF_OP_PACK3_U8, AF_OP_STEM3_POOL, AF_OP_CONV_CA, AF_OP_BLOCK_ABC, AF_OP_TSTEM_POOL3) = range(22)
+ AF_OP_PACK3_U8, AF_OP_STEM3_POOL, AF_OP_CONV_CA, AF_OP_BLOCK_ABC, AF_OP_TSTEM_POOL3, AF_OP_CONV_CPA) = range(23)
 AF_ABI_VERSION = 3
 STEM_PAD_T, STEM_PAD_H, STEM_PAD_W_LEFT, STEM_PAD_W_TOTAL, STEM_CPAD = 2, 3, 3, 8, 4
 
@@ -51,6 +51,7 @@ class Op(C.Structure):
         ("conv3", ConvDesc), ("in3", C.c_void_p), ("weight3", C.c_void_p),
         ("scale3", C.c_void_p), ("shift3", C.c_void_p),
         ("conv4", ConvDesc), ("weight4", C.c_void_p),
+        ("x_sub", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 
@@ -86,6 +87,8 @@ ABI = {
     "af_conv3d_dual_bn_act": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_void_p, C.POINTER(ConvDesc)] + [C.c_void_p] * 5
                               + [C.c_int, C.c_void_p]),
     "af_conv_ca_fusable": (C.c_int, [C.POINTER(ConvDesc)] * 3),
+    "af_conv_cpa_fusable": (C.c_int, [C.POINTER(ConvDesc)] * 2 + [C.c_int]),
+    "af_conv3d_cpa_bn_act": (C.c_int, [C.POINTER(ConvDesc)] + [C.c_void_p] * 6 + [C.c_int, C.POINTER(ConvDesc)] + [C.c_void_p] * 5),
     "af_conv3d_ca_bn_act": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_void_p, C.POINTER(ConvDesc)] + [C.c_void_p] * 6
                             + [C.POINTER(ConvDesc)] + [C.c_void_p] * 5),
     "af_conv_bc_fusable": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvDesc)]),

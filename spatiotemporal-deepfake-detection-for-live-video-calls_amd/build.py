@@ -9,9 +9,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libafhip.so")
-SOURCES = ["af_api.hip", "af_pack.hip", "af_pool.hip", "af_stem.hip", "af_stem_pool.hip", "af_stem3.hip", "af_conv.hip", "af_conv133.hip", "af_conv133g.hip", "af_conv311.hip", "af_conv_ca.hip", "af_conv111.hip", "af_ftcn.hip", "af_dual.hip", "af_conv_small.hip", "af_align.hip", "af_block_abc.hip"]
+SOURCES = ["af_api.hip", "af_pack.hip", "af_pool.hip", "af_stem.hip", "af_stem_pool.hip", "af_stem3.hip", "af_conv.hip", "af_conv133.hip", "af_conv133g.hip", "af_conv311.hip", "af_conv_ca.hip", "af_conv_cpa.hip", "af_conv111.hip", "af_ftcn.hip", "af_dual.hip", "af_conv_small.hip", "af_align.hip", "af_block_abc.hip"]
 HEADERS = [os.path.join(CSRC, "af_common.h"), os.path.join(os.path.dirname(HERE), "include", "af_hip.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-inline-asm"]
 
 
 def _stale(target, deps):

@@ -41,6 +41,9 @@ static int run_one(const af_op& op, hipStream_t s) {
         case AF_OP_CONV_BC:
             return af_conv3d_bc_bn_act(&op.conv, op.in, op.weight, op.scale, op.shift, &op.conv2, op.weight2, op.scale2, op.shift2,
                                        op.residual, op.out, op.out_ld, s);
+        case AF_OP_CONV_CPA:    /* out = the pooled trunk (whole or its even positions), aux = the next stage's `a` output */
+            return af_conv3d_cpa_bn_act(&op.conv, op.in, op.weight, op.scale, op.shift, op.residual, op.out, op.x_sub, &op.conv2,
+                                        op.weight2, op.scale2, op.shift2, op.aux, s);
         case AF_OP_CONV_CA:     /* out = the trunk, aux = the next block's `a` output */
             return af_conv3d_ca_bn_act(&op.conv, op.in, op.weight, op.in3 ? &op.conv3 : nullptr, op.in3, op.weight3, op.scale, op.shift,
                                        op.residual, op.out, &op.conv2, op.weight2, op.scale2, op.shift2, op.aux, s);

@@ -23,6 +23,16 @@ __device__ __forceinline__ void blds16(unsigned voff, const i32x4& desc, int sof
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(desc), "s"(lds_base), "s"(soff) : "memory");
 }
+// the same without saving m0 around the load (2 scalar instructions per piece instead of 4; hipcc is told that m0 is clobbered):
+// for the streaming kernels, which are bound by instruction issue at 2 waves per SIMD
+__device__ __forceinline__ void blds16_m0(unsigned voff, const i32x4& desc, int soff, unsigned lds_base) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds"
+                 : : "v"(voff), "s"(desc), "s"(lds_base), "s"(soff) : "memory", "m0");
+}
+__device__ __forceinline__ void blds16_nt_m0(unsigned voff, const i32x4& desc, int soff, unsigned lds_base) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen nt lds"
+                 : : "v"(voff), "s"(desc), "s"(lds_base), "s"(soff) : "memory", "m0");
+}
 // the same with the non-temporal cache policy: for bytes one CU reads once (a residual stream)
 __device__ __forceinline__ void blds16_nt(unsigned voff, const i32x4& desc, int soff, unsigned lds_base) {
     unsigned keep;
@@ -74,6 +84,11 @@ bool conv133g_fused_applies(const af_conv_desc* db, const af_conv_desc* dc, int 
 int conv133g_fused_run(const af_conv_desc* db, const void* in, const void* wb, const float* scale_b, const float* shift_b,
                        const af_conv_desc* dc, const void* wc, const float* scale_c, const float* shift_c, const void* residual,
                        void* out, int out_ld, hipStream_t stream);
+// af_conv_cpa.hip: the s2 -> s3 boundary - c + residual + ReLU, the temporal max-pool and the next stage's 3x1x1 a conv in one launch
+bool conv_cpa_applies(const af_conv_desc* dc, const af_conv_desc* da, int x_sub);
+int conv_cpa_run(const af_conv_desc* dc, const void* inb, const void* wc, const float* scale_c, const float* shift_c,
+                 const void* residual, void* outx, int x_sub, const af_conv_desc* da, const void* wa, const float* scale_a,
+                 const float* shift_a, void* outa, hipStream_t stream);
 // af_conv_ca.hip: c(i) -> a(i+1) across a block boundary of s2 in the time-tiled layout (the trunk slab is produced in LDS)
 bool conv_ca_applies(const af_conv_desc* dc, const af_conv_desc* d1, const af_conv_desc* da);
 int conv_ca_run(const af_conv_desc* dc, const void* inb, const void* wc, const void* in1, const void* w1, const float* scale_c,
@@ -194,11 +209,20 @@ template <> struct Vec4<AF_F32> {
     static __device__ __forceinline__ void store(void* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
     static __device__ __forceinline__ f32x4 load(const void* p) { return *reinterpret_cast<const f32x4*>(p); }
 };
+// store_relu: ReLU applied to the ROUNDED 16-bit values, two per instruction (v_pk_max_i16 against 0: a negative number has its
+// sign bit set in either encoding and is a negative integer; rounding keeps the sign, so this is relu-then-round).  +NaN is a
+// positive integer and stays NaN as under torch's clamp_min; a NaN with the sign bit set would become 0 - the input packers
+// hand on +NaN only and the arithmetic units generate +NaN, so none reaches a ReLU.
+typedef short i16x4 __attribute__((ext_vector_type(4)));
 template <> struct Vec4<AF_BF16> {
     typedef __bf16 b4 __attribute__((ext_vector_type(4)));
     static __device__ __forceinline__ void store(void* p, f32x4 v) {
         b4 o; o[0] = (__bf16)v[0]; o[1] = (__bf16)v[1]; o[2] = (__bf16)v[2]; o[3] = (__bf16)v[3];
         *reinterpret_cast<b4*>(p) = o;
+    }
+    static __device__ __forceinline__ void store_relu(void* p, f32x4 v) {
+        b4 o; o[0] = (__bf16)v[0]; o[1] = (__bf16)v[1]; o[2] = (__bf16)v[2]; o[3] = (__bf16)v[3];
+        *reinterpret_cast<i16x4*>(p) = __builtin_elementwise_max(__builtin_bit_cast(i16x4, o), i16x4{0, 0, 0, 0});
     }
     static __device__ __forceinline__ f32x4 load(const void* p) {
         b4 i = *reinterpret_cast<const b4*>(p);
@@ -211,6 +235,10 @@ template <> struct Vec4<AF_F16> {
     static __device__ __forceinline__ void store(void* p, f32x4 v) {
         h4 o; o[0] = (_Float16)v[0]; o[1] = (_Float16)v[1]; o[2] = (_Float16)v[2]; o[3] = (_Float16)v[3];
         *reinterpret_cast<h4*>(p) = o;
+    }
+    static __device__ __forceinline__ void store_relu(void* p, f32x4 v) {
+        h4 o; o[0] = (_Float16)v[0]; o[1] = (_Float16)v[1]; o[2] = (_Float16)v[2]; o[3] = (_Float16)v[3];
+        *reinterpret_cast<i16x4*>(p) = __builtin_elementwise_max(__builtin_bit_cast(i16x4, o), i16x4{0, 0, 0, 0});
     }
     static __device__ __forceinline__ f32x4 load(const void* p) {
         h4 i = *reinterpret_cast<const h4*>(p);

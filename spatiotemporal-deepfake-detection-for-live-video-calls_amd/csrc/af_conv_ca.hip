@@ -102,7 +102,7 @@ __global__ __launch_bounds__(512, 2) void conv_ca_kernel(const CAArgs a) {
         const unsigned base = lds0 + (g & 1) * WBYTES + wave * (8 * 128);
         const int soff = (g % a.kslabs) * 128;
 #pragma unroll
-        for (int i = 0; i < WPIECES; ++i) blds16(woff[i], wdesc, soff, base + i * (64 * 128));
+        for (int i = 0; i < WPIECES; ++i) blds16_m0(woff[i], wdesc, soff, base + i * (64 * 128));
     };
     auto issue_image = [&](int g) {                                  // residual slab of stage g -> image slot g % 3
         const int tile = stage_tile(g), n = tile / a.chunks, hw0 = (tile % a.chunks) * P;
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(512, 2) void conv_ca_kernel(const CAArgs a) {
 #pragma unroll
         for (int i = 0; i < XPW; ++i)
             if (wave + 8 * i < XP)
-                blds16_nt(hw0 + xp[i] < a.HW ? xoff[i] : kOutOfRange, xdesc, soff, base + i * (64 * 128));
+                blds16_nt_m0(hw0 + xp[i] < a.HW ? xoff[i] : kOutOfRange, xdesc, soff, base + i * (64 * 128));
     };
     // c weights of a stage (4 channel tiles x 2 k-halves) and the b fragments of a tile (2 row tiles x 2 k-halves):
     // global -> registers, a stage / a tile ahead
@@ -252,8 +252,7 @@ __global__ __launch_bounds__(512, 2) void conv_ca_kernel(const CAArgs a) {
                     char* cell = img + R * 128 + (((i * 2 + (fg >> 1)) ^ (frow & 7)) << 4) + (fg & 1) * 8;
                     f32x4 v = cc[i][j] * sc + sf;
                     if (!DUAL) v += Vec4<DT>::load(cell);
-                    v[0] = relu_f(v[0]); v[1] = relu_f(v[1]); v[2] = relu_f(v[2]); v[3] = relu_f(v[3]);
-                    Vec4<DT>::store(cell, v);
+                    Vec4<DT>::store_relu(cell, v);
                 }
             }
         }
@@ -311,8 +310,7 @@ __global__ __launch_bounds__(512, 2) void conv_ca_kernel(const CAArgs a) {
                 const f32x4 sc = *reinterpret_cast<const f32x4*>(bnp + 2 * a.C + i * 16 + fg * 4);
                 const f32x4 sf = *reinterpret_cast<const f32x4*>(bnp + 2 * a.C + 64 + i * 16 + fg * 4);
                 f32x4 v = acc[i][j] * sc + sf;
-                v[0] = relu_f(v[0]); v[1] = relu_f(v[1]); v[2] = relu_f(v[2]); v[3] = relu_f(v[3]);
-                if (hw0 + p < a.HW) Vec4<DT>::store(a.outa + (pos * 64 + i * 16 + fg * 4) * 2, v);
+                if (hw0 + p < a.HW) Vec4<DT>::store_relu(a.outa + (pos * 64 + i * 16 + fg * 4) * 2, v);
                 acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }

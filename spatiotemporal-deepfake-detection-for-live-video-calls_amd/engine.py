@@ -7,6 +7,7 @@ pool -> s3 -> ... -> head, with every Conv3d+BatchNorm3d(+add)(+ReLU)(+pool) gro
 launch.  PyTorch is used only to own device memory and the stream.
 """
 import ctypes as C
+import dataclasses
 import os
 from typing import Dict, List, Optional
 
@@ -169,6 +170,7 @@ class _Plan:
 
     def __init__(self, batch, code=None):
         self.batch, self.entries, self.sizes, self.code = batch, [], {}, code
+        self.boundary = None                 # set by a stage whose last launch already ran the next stage's first a conv
 
     def bc_fusable(self, b: ConvSpec, c: ConvSpec, da, db, dc) -> bool:
         """does the library run this bottleneck's b (1x3x3) and c (1x1x1 + residual) convs as one launch (af_conv3d_bc_bn_act)?
@@ -200,6 +202,31 @@ class _Plan:
             _fill_conv_desc(d3, self.batch, self.code, branch1, d_in, dc, True)
         return bool(lib.af_conv_ca_fusable(C.byref(d1), C.byref(d3) if branch1 is not None else None, C.byref(d2)))
 
+    def cpa_fusable(self, c: ConvSpec, a_next: ConvSpec, db, dc, x_sub) -> bool:
+        """does the library run the stage's last c conv (+ residual + ReLU), the temporal max-pool behind the stage and the NEXT
+        stage's first a conv as one launch (af_conv3d_cpa_bn_act)?  AF_FUSE_CPA=0 switches it off (A/B runs)."""
+        if self.code is None or os.environ.get("AF_FUSE_CPA", "0") != "1":
+            return False
+        dp = (dc[0] // 2,) + tuple(dc[1:])
+        d1, d2 = _lib.ConvDesc(), _lib.ConvDesc()
+        _fill_conv_desc(d1, self.batch, self.code, c, db, dc, True)
+        d1.tpool = 1
+        _fill_conv_desc(d2, self.batch, self.code, a_next, dp, a_next.out_dims(*dp), True)
+        return bool(lib.af_conv_cpa_fusable(C.byref(d1), C.byref(d2), x_sub))
+
+    def _boundary_fusable(self, c: ConvSpec, next_stage, db, dc) -> int:
+        """0, or the x_sub of the fused stage-boundary launch: 2 when the next stage's block 0 reads the pooled trunk only through
+        a 1x1x1 projection shortcut of stride (1,2,2) (and its a conv, which runs inside the launch), else 1."""
+        nb = next_stage.blocks[0]
+        if nb.a.pool_after_bn is not None or dc[0] % 2:
+            return 0
+        b1 = nb.branch1
+        sub = 2 if (b1 is not None and b1.pool_after_bn is None and tuple(b1.kernel) == (1, 1, 1) and tuple(b1.stride) == (1, 2, 2)
+                    and tuple(b1.pad) == (0, 0, 0) and dc[1] % 2 == 0 and dc[2] % 2 == 0) else 1
+        if b1 is None:
+            return 0                       # an identity shortcut would need the whole trunk AND block 0's residual add: not this launch
+        return sub if self.cpa_fusable(c, nb.a, db, dc, sub) else 0
+
     def abc_fusable(self, blk, d) -> bool:
         """does the library run this whole block (a, b, c + identity or stride-1 projection shortcut + ReLU) as one launch
         (af_block_abc_bn_act: the narrow blocks of SlowFast's Fast pathway)?  AF_FUSE_ABC=0 switches it off (A/B runs)."""
@@ -220,12 +247,16 @@ class _Plan:
             _fill_conv_desc(d4, self.batch, self.code, blk.branch1, d, dc, True)
         return bool(lib.af_block_abc_fusable(C.byref(d1), C.byref(d2), C.byref(d3), C.byref(d4) if blk.branch1 is not None else None))
 
-    def stage(self, stage, d, cur, nxt, a_buf, b_buf, last_ld=None, tpool_last=False):
+    def stage(self, stage, d, cur, nxt, a_buf, b_buf, last_ld=None, tpool_last=False, next_stage=None):
         """One pathway's ResStage.  ``last_ld``: row stride of the stage's final output (room for the lateral's
-        channels).  Returns (dims, channels, buffer holding the output, the other trunk buffer)."""
+        channels); ``next_stage`` (with ``tpool_last``): the stage behind the temporal pool, whose first a conv may ride in this
+        stage's last launch.  Returns (dims, channels, buffer holding the output, the other trunk buffer)."""
         c = None
         nblk = len(stage.blocks)
-        a_done = False                       # this block's a conv was run by the previous block's fused c -> a launch
+        # this block's a conv was run by the previous block's fused c -> a launch (or, block 0, by the previous STAGE's last one)
+        bnd, self.boundary = self.boundary, None
+        a_done = bnd is not None
+        sub_first = bool(bnd and bnd.get("sub"))
         for bi, blk in enumerate(stage.blocks):
             last = bi == nblk - 1
             if not a_done and not (tpool_last and last) and self.abc_fusable(blk, d):
@@ -284,7 +315,14 @@ class _Plan:
             # the temporal max-pool after s2 rides in the epilogue of s2's last conv when it can
             tp = tpool_last and last and blk.branch1 is None and dc[0] % 2 == 0
             dstore = (dc[0] // 2,) + tuple(dc[1:]) if tp else dc
-            if blk.branch1 is not None and blk.branch1.pool_after_bn is None:
+            if blk.branch1 is not None and blk.branch1.pool_after_bn is None and bi == 0 and sub_first:
+                # the previous stage's last launch stored the trunk only where this stride-(1,2,2) shortcut reads it, packed:
+                # the same weights as a stride-1 convolution over that tensor
+                b1 = dataclasses.replace(blk.branch1, stride=(1, 1, 1))
+                dsub = (d[0], d[1] // 2, d[2] // 2)
+                assert b1.out_dims(*dsub) == dc
+                self.add(kind="dual", cv=blk.c, cv2=b1, din=db, din2=dsub, dout=dc, src=c_src, src2=cur, dst=nxt, ld=ld)
+            elif blk.branch1 is not None and blk.branch1.pool_after_bn is None:
                 # c conv + projection shortcut in one launch; no shortcut tensor
                 assert blk.branch1.out_dims(*d) == dc
                 if (not last and ld == blk.c.cout and stage.blocks[bi + 1].a.pool_after_bn is None
@@ -304,6 +342,14 @@ class _Plan:
                 self.add(kind="ca", cv=blk.c, cv2=nxa, din=db, dout=dc, src=c_src, res=res_src, dst=nxt, dst2=a_buf)
                 self.need(a_buf, nxa.out_dims(*dc), nxa.cout)
                 a_done = True
+            elif tp and next_stage is not None and res_src == cur and ld == blk.c.cout and self._boundary_fusable(blk.c, next_stage, db, dc):
+                # s2 -> s3: c + residual + ReLU, the temporal pool and the next stage's first a conv in one launch; the pooled trunk
+                # is stored only where the next stage's projection shortcut reads it
+                nb = next_stage.blocks[0]
+                sub = self._boundary_fusable(blk.c, next_stage, db, dc)
+                self.add(kind="cpa", cv=blk.c, cv2=nb.a, din=db, dout=dc, src=c_src, res=res_src, dst=nxt, dst2=a_buf, x_sub=sub, tpool=True)
+                self.need(a_buf, nb.a.out_dims(*dstore), nb.a.cout)
+                self.boundary = {"sub": sub == 2}
             else:
                 self.add(kind="conv", cv=blk.c, din=db, dout=dc, src=c_src, dst=nxt, res=res_src, ld=ld, tpool=tp)
             self.need(nxt, dstore, ld)
@@ -352,7 +398,8 @@ class Engine:
         fuse_tpool = _is_pool(spec.pool_after_s2, (2, 1, 1), (2, 1, 1), (0, 0, 0))
         c = spec.stem.cout
         for si, stage in enumerate(spec.stages):
-            d, c, cur, nxt = plan.stage(stage, d, cur, nxt, "A", "B", tpool_last=(fuse_tpool and si == 0))
+            d, c, cur, nxt = plan.stage(stage, d, cur, nxt, "A", "B", tpool_last=(fuse_tpool and si == 0),
+                                        next_stage=spec.stages[1] if (si == 0 and len(spec.stages) > 1) else None)
             if si == 0 and not plan.entries[-1].get("tpool"):
                 # pathway0_pool as its own launch (odd frame counts / other pool shapes)
                 d2 = _pool_out(d, spec.pool_after_s2)
@@ -547,6 +594,22 @@ class Engine:
                 op.out_ld = cvc.cout
                 self.op_names.append(cvc.conv + ("+branch1" if e.get("cv3") is not None else "") + "->" + cva.conv.split("resnet.")[-1])
                 self.op_macs.append(batch * macs)
+            elif kind == "cpa":
+                cvc, cva = e["cv"], e["cv2"]
+                dp = (e["dout"][0] // 2,) + tuple(e["dout"][1:])
+                op.kind, op.tag = _lib.AF_OP_CONV_CPA, TAG_CONV_CA
+                fill_conv(op.conv, cvc, e["din"], e["dout"], True)
+                op.conv.tpool = 1
+                fill_conv(op.conv2, cva, dp, cva.out_dims(*dp), True)
+                op.weight, op.scale, op.shift = (weights.w[cvc.conv].data_ptr(), weights.scale[cvc.conv].data_ptr(),
+                                                 weights.shift[cvc.conv].data_ptr())
+                op.weight2, op.scale2, op.shift2 = (weights.w[cva.conv].data_ptr(), weights.scale[cva.conv].data_ptr(),
+                                                    weights.shift[cva.conv].data_ptr())
+                op.residual = self.buf[e["res"]].data_ptr()
+                op.aux = self.buf[e["dst2"]].data_ptr()
+                op.out_ld, op.x_sub = cvc.cout, e["x_sub"]
+                self.op_names.append(cvc.conv + "+pool->" + cva.conv.split("resnet.")[-1])
+                self.op_macs.append(batch * (cvc.macs(*e["din"]) + cva.macs(*dp)))
             elif kind == "abc":
                 cva, cvb, cvc = e["cv"], e["cv2"], e["cv3"]
                 op.kind, op.tag = _lib.AF_OP_BLOCK_ABC, TAG_BLOCK_ABC
@@ -806,6 +869,8 @@ class Engine:
             shape = (op.conv2.n, op.conv2.to, op.conv2.ho, op.conv2.wo, op.out_ld or op.conv2.cout)
         elif op.kind == _lib.AF_OP_BLOCK_ABC:
             shape = (op.conv3.n, op.conv3.to, op.conv3.ho, op.conv3.wo, op.out_ld or op.conv3.cout)
+        elif op.kind == _lib.AF_OP_CONV_CPA:       # the pooled trunk, or (x_sub == 2) its even (h, w) positions
+            shape = (op.conv.n, op.conv.to // 2, op.conv.ho // op.x_sub, op.conv.wo // op.x_sub, op.conv.cout)
         elif op.kind == _lib.AF_OP_CONV_CA:        # the trunk
             shape = (op.conv.n, op.conv.to, op.conv.ho, op.conv.wo, op.conv.cout)
         elif op.kind in (_lib.AF_OP_STEM, _lib.AF_OP_CONV, _lib.AF_OP_CONV_DUAL, _lib.AF_OP_TSTEM):

@@ -195,6 +195,32 @@ def conv_ca(b_ndhwc, wc_oidhw, bn_c, res_ndhwc, wa_oidhw, bn_a, dtype, x0_ndhwc=
     return x, a_out
 
 
+def conv_cpa(b_ndhwc, wc_oidhw, bn_c, res_ndhwc, wa_oidhw, bn_a, dtype, x_sub):
+    """x = relu(bn_c(conv1x1x1(b)) + res), xp = max over frame pairs, a_out = relu(bn_a(conv3x1x1(xp))) as one
+    af_conv3d_cpa_bn_act launch -> (xp or its even (h, w) positions, a_out); None if the library does not fuse this pair."""
+    L = lib()
+    code = L.DTYPE_CODES[dtype]
+    n, t, h, w, cmid = b_ndhwc.shape
+    ctrunk, cout_a = wc_oidhw.shape[0], wa_oidhw.shape[0]
+    dc, da = L.ConvDesc(), L.ConvDesc()
+    dc.n, dc.t, dc.h, dc.w, dc.cin, dc.cout = n, t, h, w, cmid, ctrunk
+    dc.kt = dc.kh = dc.kw = dc.st = dc.sh = dc.sw = 1
+    dc.to, dc.ho, dc.wo, dc.relu, dc.dtype, dc.tpool = t, h, w, 1, code, 1
+    da.n, da.t, da.h, da.w, da.cin, da.cout = n, t // 2, h, w, ctrunk, cout_a
+    da.kt, da.kh, da.kw, da.st, da.sh, da.sw, da.pt, da.ph, da.pw = 3, 1, 1, 1, 1, 1, 1, 0, 0
+    da.to, da.ho, da.wo, da.relu, da.dtype = t // 2, h, w, 1, code
+    if not L.lib.af_conv_cpa_fusable(C.byref(dc), C.byref(da), x_sub):
+        return None
+    pc, pa = _pack_plain(wc_oidhw, dtype), _pack_plain(wa_oidhw, dtype)
+    xs = (n, t // 2, h // 2, w // 2, ctrunk) if x_sub == 2 else (n, t // 2, h, w, ctrunk)
+    x = torch.full(xs, 7.0, dtype=TORCH_DT[dtype], device="cuda")
+    a_out = torch.full((n, t // 2, h, w, cout_a), 7.0, dtype=TORCH_DT[dtype], device="cuda")
+    L.check(L.lib.af_conv3d_cpa_bn_act(C.byref(dc), _p(b_ndhwc), _p(pc), _p(bn_c[0]), _p(bn_c[1]), _p(res_ndhwc), _p(x), x_sub,
+                                       C.byref(da), _p(pa), _p(bn_a[0]), _p(bn_a[1]), _p(a_out), _stream()), "conv3d_cpa_bn_act")
+    torch.cuda.current_stream().synchronize()
+    return x, a_out
+
+
 def _pack_scaled(w_oidhw, row_scale, dtype):
     L = lib()
     code = L.DTYPE_CODES[dtype]

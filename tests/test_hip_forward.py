@@ -224,16 +224,18 @@ def test_small_network_vs_oracle_all_dtypes():
         assert err <= tol, (dtype, err)
 
 
-def test_non_finite_pixel_gives_nan_logit_like_reference():
+@pytest.mark.parametrize("nan", [float("nan"), -float("nan")], ids=["nan", "nan_with_sign_bit"])
+def test_non_finite_pixel_gives_nan_logit_like_reference(nan):
     """A NaN pixel must not turn into a plausible score: in the reference it survives Conv3d, eval BN, ReLU (clamp_min keeps
     NaN), MaxPool3d and AvgPool3d and the clip's logit is NaN; the other clips of the batch are untouched.  Same shrunken
-    network as above (every conv kernel family is on the path); the oracle states the expectation."""
+    network as above (every conv kernel family is on the path); the oracle states the expectation.  The NaN with its sign bit
+    set is what x86 code hands over for 0/0: the packed 16-bit ReLU would zero it, so the input packers clear the sign."""
     clip_size, size = 8, 64
     from af_mi355x.arch import i3d_r50_spec
     sd = synth.synthetic_state_dict(i3d_r50_spec(clip_size, size), seed=5)
     u8 = synth.synthetic_clips_u8(3, seed=9, kind="smooth", num_frames=clip_size, size=size)
     x = synth.normalize_like_callers(u8)
-    x[1, 2, 3, 17, 40] = float("nan")
+    x[1, 2, 3, 17, 40] = nan
     want = oracle.forward(sd, x, num_frames=clip_size, crop=size)
     assert torch.isnan(want[1]).all() and torch.isfinite(want[[0, 2]]).all()
     for dtype, tol in (("f32", 1e-4), ("f16", 1e-3), ("bf16", 1e-2)):

@@ -617,6 +617,50 @@ def test_fused_c_a_vs_oracle(name, ctrunk, dims, dtype):
 
 
 @pytest.mark.parametrize("dtype", ["f16", "bf16"])
+@pytest.mark.parametrize("x_sub", [2, 1])
+@pytest.mark.parametrize("name,ctrunk,dims", [
+    ("s2_to_s3", 256, (3, 32, 56, 56)),           # 4 K slabs; 28 x 14 tiles per clip (2 rows x 4 columns each): 1 176 >= 4 per CU
+    ("two_slabs_odd_patch_count", 128, (3, 32, 52, 60)),
+])
+def test_fused_c_pool_a_vs_oracle(name, ctrunk, dims, x_sub, dtype):
+    """af_conv3d_cpa_bn_act - the s2 -> s3 boundary in one launch: x = relu(bn_c(c(b)) + res), pathway0_pool (max over frame
+    pairs), a_out = relu(bn_a(a3x1x1(pooled))) - against the oracle's conv_bn_act / max_pool3d in fp64; the pooled trunk is
+    rounded to the storage type on both sides before the temporal conv (rounding is monotonic: pooling before or after it is
+    the same).  x_sub = 2: only the even (h, w) positions of the pooled trunk are stored, packed - what the next stage's
+    stride-(1,2,2) projection shortcut reads."""
+    seed = 5200 + sum(map(ord, name))
+    n, t, h, w = dims
+    lay = [("c.weight", (ctrunk, 64, 1, 1, 1), "float32"), ("a.weight", (128, ctrunk, 3, 1, 1), "float32")]
+    for p_, ch in (("c_bn", ctrunk), ("a_bn", 128)):
+        lay += [(p_ + s_, (ch,), "float32") for s_ in (".weight", ".bias", ".running_mean", ".running_var")]
+    sd = synth.fill_layout(lay, seed)
+    tdt = hh.TORCH_DT[dtype]
+    b = synth.synthetic_tensor((n, 64, t, h, w), seed).to(tdt).float()
+    res = synth.synthetic_tensor((n, ctrunk, t, h, w), seed + 1).to(tdt).float()
+    for k in ("c.weight", "a.weight"):
+        sd[k] = sd[k].to(tdt).float()
+    sd64 = {k: v.double() for k, v in sd.items()}
+    x = F.relu(oracle.conv_bn_act(b.double(), sd64["c.weight"], sd64, "c_bn", (1, 1, 1), (0, 0, 0), False) + res.double())
+    xp = F.max_pool3d(x, (2, 1, 1), (2, 1, 1))
+    xr = xp.to(tdt).double()                                    # the one rounding of the trunk
+    want_a = oracle.conv_bn_act(xr, sd64["a.weight"], sd64, "a_bn", (1, 1, 1), (1, 0, 0), True)
+    out = hh.conv_cpa(hh.to_ndhwc(b, dtype), sd["c.weight"], hh.fold_bn(sd, "c_bn"), hh.to_ndhwc(res, dtype), sd["a.weight"],
+                      hh.fold_bn(sd, "a_bn"), dtype, x_sub)
+    assert out is not None, "the library should fuse this pair"
+    # frames with an odd row count or a width that is not a multiple of 4 keep their two launches
+    assert hh.conv_cpa(hh.to_ndhwc(b[..., :w - 2].contiguous(), dtype), sd["c.weight"], hh.fold_bn(sd, "c_bn"),
+                       hh.to_ndhwc(res[..., :w - 2].contiguous(), dtype), sd["a.weight"], hh.fold_bn(sd, "a_bn"), dtype, x_sub) is None
+    got_x, got_a = hh.to_ncdhw(out[0]).double(), hh.to_ncdhw(out[1]).double()
+    want_x = xp[..., ::2, ::2] if x_sub == 2 else xp
+    tol = {"f16": 1.5e-3, "bf16": 1.2e-2}[dtype]
+    assert got_x.shape == want_x.shape
+    ex = (got_x - want_x).abs().max().item()
+    assert ex <= tol * (xp.abs().max().item() + 1e-9), "%s[%s] trunk err %.3e" % (name, dtype, ex)
+    ea = (got_a - want_a).abs().max().item()
+    assert ea <= 1.5 * tol * (want_a.abs().max().item() + 1e-9), "%s[%s] a err %.3e" % (name, dtype, ea)   # a trunk value on a rounding boundary may round the other way
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
 def test_fused_c_shortcut_a_vs_oracle(dtype):
     """the projection-block form of af_conv3d_ca_bn_act: x = relu(bn_c(c(b)) + bn_1(branch1(x0))), a_out = relu(bn_a(a3x1x1(x))) -
     block 0 of s2 and the first conv of block 1 in one launch.  The BN scales are folded into the 16-bit weights there (two convs
