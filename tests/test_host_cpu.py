@@ -364,13 +364,11 @@ def test_hand_counted_vmcnt_kernels_have_no_spills_and_no_early_use_of_uncounted
             for j in range(i + 1, len(lines)):
                 u = lines[j].strip()
                 if not u or u.startswith(";") or u.startswith("."):
-                    if re.match(r"\.LBB\d+_\d+:", u):
-                        break                                   # a label: control flow merges, the linear scan ends
-                    continue
+                    continue                                    # (labels: the scan follows the fall-through path across them)
                 if u.startswith("s_waitcnt") and "vmcnt" in u:
                     break
-                if u.startswith(("s_cbranch", "s_branch", "s_endpgm", "s_setpc")):
-                    break
+                if u.startswith(("s_branch", "s_endpgm", "s_setpc")):
+                    break                                       # conditional branches: the not-taken path continues below
                 # the address operand of ANOTHER load may reuse no destination register either; any mention counts
                 hit = dest & _regs_of(u)
                 assert not hit, "%s: v%s is the destination of a pending uncounted load (line %d: %s) but is touched by line %d: %s" % (
