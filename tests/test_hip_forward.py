@@ -271,6 +271,30 @@ def test_config1_batch16_at_its_own_dtype(weights0, dtype):
     assert err <= LOGIT_TOL[dtype], (dtype, err)
 
 
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+def test_fused_stage_boundary_engine_matches_reference(weights0, dtype, monkeypatch):
+    """AF_FUSE_CPA=1: s2's last c conv, pathway0_pool and s3's first a conv run as ONE launch (af_conv3d_cpa_bn_act) and s3's
+    projection shortcut reads the packed even-position trunk with stride 1.  Off by default (measured slower), so the
+    plan is exercised here: the B=16 golden batch against the reference's own logits, and the op list shows the fused launch."""
+    from af_mi355x import _lib
+    monkeypatch.setenv("AF_FUSE_CPA", "1")
+    g = load_json("f1b_logits.json")["batch16"]
+    u8 = synth.synthetic_clips_u8(16, seed=g["seed"], kind=g["kind"])
+    clf = Classifier(precision=dtype)
+    clf.network.load_state_dict(weights0)
+    clf = clf.cuda().eval()
+    with torch.inference_mode():
+        y = clf.network.forward_clips_u8(u8.cuda())["final_output"].cpu().flatten()
+    eng = clf.network._engines[(dtype, 16, (32, 224, 224))]
+    kinds = [eng.ops[i].kind for i in range(eng.n_ops)]
+    assert kinds.count(_lib.AF_OP_CONV_CPA) == 1
+    cpa = eng.ops[kinds.index(_lib.AF_OP_CONV_CPA)]
+    assert cpa.x_sub == 2 and cpa.conv2.cout == 128
+    err = (y - torch.tensor(g["logits_f32"])).abs().max().item()
+    print("B=16 %s with the fused s2 -> s3 boundary: max|d| %.3e" % (dtype, err))
+    assert err <= LOGIT_TOL[dtype], (dtype, err)
+
+
 @pytest.mark.parametrize("dtype", ["f32", "f16", "bf16"])
 def test_hot_checkpoint_logits(dtype):
     """Second weight seed with |logit| 18..33 that moves between clips (F1b "hot"): 8 clips in one batch."""
