@@ -15,7 +15,7 @@ def env_rank_world() -> Tuple[int, int, int]:
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
-def init(backend: str = None, timeout_s: float = 120.0) -> Tuple[int, int, int]:
+def init(backend: str = None, timeout_s: float = 300.0) -> Tuple[int, int, int]:
     """Initialises torch.distributed from the torchrun environment (no-op for a single process).
     With the RCCL backend the process group is bound to this rank's GPU (``device_id``), so the communicator is created
     eagerly on the right device and barriers need no device guess; ``timeout_s`` bounds the rendezvous and every
