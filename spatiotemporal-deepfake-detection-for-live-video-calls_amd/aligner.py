@@ -108,7 +108,10 @@ def _pool():
 
 def _copy_group(pairs):
     for dst, im in pairs:
-        np.copyto(dst, im.reshape(-1) if im.flags.c_contiguous else np.ascontiguousarray(im).reshape(-1))
+        if im.flags.c_contiguous:
+            np.copyto(dst, im.reshape(-1))
+        else:                                    # a column-clipped view: one strided copy, row by row, no temporary
+            np.copyto(dst.reshape(im.shape), im)
 
 
 class FasterCropAlignXRay:
@@ -156,15 +159,16 @@ class FasterCropAlignXRay:
         out = torch.empty((len(images), self.image_size, self.image_size, 3), dtype=torch.uint8, device=dev)
         if len(images) == 0:
             return out
-        # only the crop rows the warp can touch are uploaded: the destination square maps to a parallelogram of the canvas;
-        # a crop cut to rows [r0, r1) is the same picture as that shorter crop pasted r0 rows lower (everything else it would
-        # have covered is never sampled), so the kernel's frame table takes (y + r0, r1 - r0) and nothing else changes
+        # only the part of a crop the warp can touch is uploaded: the destination square maps to a parallelogram of the canvas;
+        # a crop cut to rows [r0, r1) x columns [c0, c1) is the same picture as that smaller crop pasted (c0, r0) further in
+        # (everything else it would have covered is never sampled), so the kernel's frame table takes the moved origin and the
+        # smaller size and nothing else changes
         for i, im in enumerate(images):
             x, y = int(diff[i][0]), int(diff[i][1])
             if im.ndim == 3 and (x < 0 or y < 0 or x + im.shape[1] > w or y + im.shape[0] > h):
                 # numpy refuses new_image[y:y+ih, x:x+iw] = image for a crop that sticks out of the canvas
                 raise ValueError("aligner: frame %d (%dx%d at %d,%d) does not fit the %dx%d canvas" % (i, im.shape[1], im.shape[0], x, y, w, h))
-        images, diff = self._clip_rows(images, diff, tfm)
+        images, diff = self._clip_rect(images, diff, tfm)
         with torch.cuda.device(dev):
             crops, offs, slot = self.stage_crops_ring(images, dev)
             self.launch_warps(crops, offs, [im.shape for im in images], diff, h, w, tfm, out)
@@ -173,26 +177,34 @@ class FasterCropAlignXRay:
             self._ring.done[slot] = ev
         return out
 
-    def _clip_rows(self, images: Sequence[np.ndarray], diff: np.ndarray, tfm: np.ndarray):
-        """rows of the canvas the size x size destination can sample (bilinear taps, fixed-point rounding: 3 rows of margin)
-        -> per frame the crop rows inside that range (views, no copy) and the paste offsets moved down accordingly"""
+    def _clip_rect(self, images: Sequence[np.ndarray], diff: np.ndarray, tfm: np.ndarray):
+        """the rectangle of the canvas the size x size destination can sample (bilinear taps, fixed-point rounding: 3 pixels of
+        margin) -> per frame the part of the crop inside it (a view, no copy) and the paste offset moved accordingly.  (Round 2
+        cut rows only - a contiguous view; the columns halve the bytes once more and the strided copy into the pinned slot costs
+        less than the PCIe time they would have taken.)"""
         m = np.asarray(tfm, dtype=np.float64).reshape(2, 3)
         det = m[0, 0] * m[1, 1] - m[0, 1] * m[1, 0]
         if not np.isfinite(det) or abs(det) < 1e-12:
-            return images, diff                              # singular map: OpenCV's D = 0 path samples around one point; keep all rows
+            return images, diff                              # singular map: OpenCV's D = 0 path samples around one point; keep everything
         s = float(self.image_size - 1)
         corners = np.array([[0.0, 0.0], [s, 0.0], [0.0, s], [s, s]])
-        # dst = M [x y 1]^T  ->  src y = ((-m10) (dx - m02) + m00 (dy - m12)) / det
-        ys = (-m[1, 0] * (corners[:, 0] - m[0, 2]) + m[0, 0] * (corners[:, 1] - m[1, 2])) / det
-        lo, hi = int(np.floor(ys.min())) - 3, int(np.ceil(ys.max())) + 4
+        # dst = M [x y 1]^T  ->  src = M^-1 (dst - t)
+        dx, dy = corners[:, 0] - m[0, 2], corners[:, 1] - m[1, 2]
+        xs = (m[1, 1] * dx - m[0, 1] * dy) / det
+        ys = (-m[1, 0] * dx + m[0, 0] * dy) / det
+        if not (np.isfinite(xs).all() and np.isfinite(ys).all()):
+            return images, diff
+        ylo, yhi = int(np.floor(ys.min())) - 3, int(np.ceil(ys.max())) + 4
+        xlo, xhi = int(np.floor(xs.min())) - 3, int(np.ceil(xs.max())) + 4
         out_images, out_diff = [], np.array(diff, dtype=np.int64, copy=True)
         for i, im in enumerate(images):
-            y0 = int(out_diff[i][1])
-            r0, r1 = max(0, lo - y0), min(im.shape[0], hi - y0)
-            if r1 <= r0:                                     # the warp never reaches this crop: one row keeps the frame table valid
-                r0, r1 = 0, 1
-            out_images.append(im[r0:r1])
-            out_diff[i][1] = y0 + r0
+            x0, y0 = int(out_diff[i][0]), int(out_diff[i][1])
+            r0, r1 = max(0, ylo - y0), min(im.shape[0], yhi - y0)
+            c0, c1 = max(0, xlo - x0), min(im.shape[1], xhi - x0)
+            if r1 <= r0 or c1 <= c0:                         # the warp never reaches this crop: one pixel keeps the frame table valid
+                r0, r1, c0, c1 = 0, 1, 0, 1
+            out_images.append(im[r0:r1, c0:c1])
+            out_diff[i][0], out_diff[i][1] = x0 + c0, y0 + r0
         return out_images, out_diff
 
     @staticmethod
