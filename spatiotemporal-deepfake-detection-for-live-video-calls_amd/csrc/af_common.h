@@ -67,8 +67,11 @@ __device__ __forceinline__ i32x4 make_desc(const char* base) {
 
 // ReLU and pooling max with torch's NaN behaviour: a NaN activation stays NaN through clamp_min / max_pool, so a clip
 // with a non-finite pixel yields a NaN logit (as in the reference) instead of a plausible score
-__device__ __forceinline__ float relu_f(float v) { return v < 0.f ? 0.f : v; }
-__device__ __forceinline__ float max_nan(float m, float x) { return (x > m || x != x) ? x : m; }
+// (gfx950 has the IEEE-754-2019 maximum / minimum - v_maximum3_f32 / v_minimum3_f32 - which return NaN when an operand is NaN:
+//  one instruction each, where a compare + select took two to four and the v_max3 / v_min3 forms needed separate NaN flags)
+__device__ __forceinline__ float relu_f(float v) { return __builtin_elementwise_maximum(v, 0.f); }
+__device__ __forceinline__ float max_nan(float m, float x) { return __builtin_elementwise_maximum(m, x); }
+__device__ __forceinline__ float min_nan(float m, float x) { return __builtin_elementwise_minimum(m, x); }
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -209,11 +212,7 @@ template <> struct Vec4<AF_F32> {
     static __device__ __forceinline__ void store(void* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
     static __device__ __forceinline__ f32x4 load(const void* p) { return *reinterpret_cast<const f32x4*>(p); }
 };
-// store_relu: ReLU applied to the ROUNDED 16-bit values, two per instruction (v_pk_max_i16 against 0: a negative number has its
-// sign bit set in either encoding and is a negative integer; rounding keeps the sign, so this is relu-then-round).  +NaN is a
-// positive integer and stays NaN as under torch's clamp_min; a NaN with the sign bit set would become 0 - the input packers
-// hand on +NaN only and the arithmetic units generate +NaN, so none reaches a ReLU.
-typedef short i16x4 __attribute__((ext_vector_type(4)));
+// store_relu: ReLU (NaN kept, like torch's clamp_min) + the one rounding + store
 template <> struct Vec4<AF_BF16> {
     typedef __bf16 b4 __attribute__((ext_vector_type(4)));
     static __device__ __forceinline__ void store(void* p, f32x4 v) {
@@ -221,8 +220,8 @@ template <> struct Vec4<AF_BF16> {
         *reinterpret_cast<b4*>(p) = o;
     }
     static __device__ __forceinline__ void store_relu(void* p, f32x4 v) {
-        b4 o; o[0] = (__bf16)v[0]; o[1] = (__bf16)v[1]; o[2] = (__bf16)v[2]; o[3] = (__bf16)v[3];
-        *reinterpret_cast<i16x4*>(p) = __builtin_elementwise_max(__builtin_bit_cast(i16x4, o), i16x4{0, 0, 0, 0});
+        v[0] = relu_f(v[0]); v[1] = relu_f(v[1]); v[2] = relu_f(v[2]); v[3] = relu_f(v[3]);
+        store(p, v);
     }
     static __device__ __forceinline__ f32x4 load(const void* p) {
         b4 i = *reinterpret_cast<const b4*>(p);
@@ -237,8 +236,8 @@ template <> struct Vec4<AF_F16> {
         *reinterpret_cast<h4*>(p) = o;
     }
     static __device__ __forceinline__ void store_relu(void* p, f32x4 v) {
-        h4 o; o[0] = (_Float16)v[0]; o[1] = (_Float16)v[1]; o[2] = (_Float16)v[2]; o[3] = (_Float16)v[3];
-        *reinterpret_cast<i16x4*>(p) = __builtin_elementwise_max(__builtin_bit_cast(i16x4, o), i16x4{0, 0, 0, 0});
+        v[0] = relu_f(v[0]); v[1] = relu_f(v[1]); v[2] = relu_f(v[2]); v[3] = relu_f(v[3]);
+        store(p, v);
     }
     static __device__ __forceinline__ f32x4 load(const void* p) {
         h4 i = *reinterpret_cast<const h4*>(p);

@@ -420,7 +420,7 @@ __global__ __launch_bounds__(WN * WM * KS * 64, MINW) void conv_igemm_kernel(con
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             const float x = a.relu ? relu_f(t[q]) : t[q];
-                            v[e + q] = (p4 == 0 || x > v[e + q] || x != x) ? x : v[e + q];   // NaN propagates like ATen's max_pool
+                            v[e + q] = p4 == 0 ? x : max_nan(v[e + q], x);   // NaN propagates like ATen's max_pool
                         }
                     }
                 if (live && m < a.M && ch0 < a.Cout) {
@@ -464,7 +464,7 @@ __global__ __launch_bounds__(WN * WM * KS * 64, MINW) void conv_igemm_kernel(con
                     for (int e = 0; e < EPC; ++e) {
                         float x0 = v[0][e], x1 = v[1][e];
                         if (a.relu) { x0 = relu_f(x0); x1 = relu_f(x1); }
-                        oe[e] = E::from_f32((x1 > x0 || x1 != x1) ? x1 : x0);      // NaN propagates like ATen's max_pool
+                        oe[e] = E::from_f32(max_nan(x0, x1));      // NaN propagates like ATen's max_pool
                     }
                     __builtin_nontemporal_store(__builtin_bit_cast(u32x4, o), reinterpret_cast<u32x4*>(a.out + ((m >> 1) * a.out_ld + ch0) * ES));
                 }

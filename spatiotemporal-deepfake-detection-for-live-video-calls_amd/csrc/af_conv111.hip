@@ -285,7 +285,7 @@ __global__ __launch_bounds__(512, 1) void conv111_kernel(const C111Args a) {
                     }
                     if (TPOOL) {
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = (v[e] > keep[it][e] || v[e] != v[e]) ? v[e] : keep[it][e];   // NaN propagates like ATen's max_pool
+                        for (int e = 0; e < 8; ++e) v[e] = max_nan(keep[it][e], v[e]);   // NaN propagates like ATen's max_pool
                     }
                     uint4 ov;
                     typename E::type* oe = reinterpret_cast<typename E::type*>(&ov);

@@ -146,20 +146,14 @@ __global__ __launch_bounds__(256) void tstem_kernel(const TStemArgs a) {
         for (int i = 0; i < 4; ++i) {
             // max over the window of bn(x) = bn(max x) for a scale >= 0 and bn(min x) for a scale < 0 (x -> x*s + b is
             // monotonic, so the selected member's image IS the maximum image, bit for bit): one FMA instead of four and
-            // plain 3-input max / min on the raw accumulators; a NaN member (unordered compare) makes the result NaN
+            // NaN-propagating max / min (v_maximum3_f32 / v_minimum3_f32) on the raw accumulators: a NaN member makes the result NaN
             // like ATen's max_pool.
             f32x4 v;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float x0 = acc[0][i][e], x1 = acc[1][i][e], x2 = acc[2][i][e], x3 = acc[3][i][e];
-                float mx, mn;
-                asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mx) : "v"(x0), "v"(x1), "v"(x2));
-                asm("v_max_f32 %0, %1, %2" : "=v"(mx) : "v"(mx), "v"(x3));
-                asm("v_min3_f32 %0, %1, %2, %3" : "=v"(mn) : "v"(x0), "v"(x1), "v"(x2));
-                asm("v_min_f32 %0, %1, %2" : "=v"(mn) : "v"(mn), "v"(x3));
-                const float y = (sc[i][e] >= 0.f ? mx : mn) * sc[i][e] + sf[i][e];
-                const bool nan = __builtin_isunordered(x0, x1) || __builtin_isunordered(x2, x3);
-                v[e] = relu_f(nan ? __builtin_nanf("") : y);
+                const float mx = max_nan(max_nan(x0, x1), max_nan(x2, x3)), mn = min_nan(min_nan(x0, x1), min_nan(x2, x3));
+                v[e] = relu_f((sc[i][e] >= 0.f ? mx : mn) * sc[i][e] + sf[i][e]);
             }
             if (DT == AF_F32) {
                 if (live) Vec4<DT>::store(a.out + (opix * 64 + i * 16 + fg * 4) * ES, v);
@@ -275,12 +269,11 @@ __global__ __launch_bounds__(256, 2) void tstem_pool3_kernel(const TStemP3Args a
     uint4 rowc[3][2], rown[3][2];
     load_row(cur.base, cur.qy, cur.coff, 0, rowc);
     for (; tile < (unsigned)a.tiles; tile += (unsigned)nwaves) {
-        float mx[4][4], mn[4][4];
-        bool nanf[4][4];                                       // per output element: a member was NaN (-> NaN, like ATen's max_pool)
-#pragma unroll
+        float mx[4][4], mn[4][4];                              // NaN-propagating max / min (v_maximum3_f32 / v_minimum3_f32): a NaN member
+#pragma unroll                                                 // makes the result NaN, like ATen's max_pool
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { mx[i][e] = -INFINITY; mn[i][e] = INFINITY; nanf[i][e] = false; }
+            for (int e = 0; e < 4; ++e) { mx[i][e] = -INFINITY; mn[i][e] = INFINITY; }
         const unsigned ntile = tile + (unsigned)nwaves < (unsigned)a.tiles ? tile + (unsigned)nwaves : tile;
         const Where nxt = locate(ntile);
 #pragma unroll 1
@@ -305,9 +298,9 @@ __global__ __launch_bounds__(256, 2) void tstem_pool3_kernel(const TStemP3Args a
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float xl = lo[i][e], xh = hi[i][e];
-                        mx[i][e] = __builtin_fmaxf(mx[i][e], __builtin_fmaxf(xl, xh));     // (v_max3_f32: NaN operands are ignored,
-                        mn[i][e] = __builtin_fminf(mn[i][e], __builtin_fminf(xl, xh));     //  the flag below carries them)
-                        nanf[i][e] = nanf[i][e] || __builtin_isunordered(lo[i][e], hi[i][e]);
+                        // (builtins, not inline asm: hipcc does not space an asm statement behind the MFMA whose result it reads)
+                        mx[i][e] = max_nan(mx[i][e], max_nan(xl, xh));
+                        mn[i][e] = min_nan(mn[i][e], min_nan(xl, xh));
                     }
                 __builtin_amdgcn_sched_barrier(0);                 // one pair's 8 accumulators live at a time
             }
@@ -321,8 +314,7 @@ __global__ __launch_bounds__(256, 2) void tstem_pool3_kernel(const TStemP3Args a
             f32x4 v;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float y = (sc[i][e] >= 0.f ? mx[i][e] : mn[i][e]) * sc[i][e] + sf[i][e];
-                v[e] = relu_f(nanf[i][e] ? __builtin_nanf("") : y);
+                v[e] = relu_f((sc[i][e] >= 0.f ? mx[i][e] : mn[i][e]) * sc[i][e] + sf[i][e]);
             }
             const int c = i * 2 + (fg >> 1);
             Vec4<DT>::store(patch + frow * 128 + ((c ^ (frow & 7)) * 16) + (fg & 1) * 8, v);

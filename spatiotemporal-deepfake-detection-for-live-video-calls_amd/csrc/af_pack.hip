@@ -72,10 +72,7 @@ __global__ void pack_input_kernel(Src src, int n, int t, int h, int w, char* __r
 struct SrcF32 {
     const float* p; long long sn, sc, st, sh, sw;
     __device__ float operator()(long long b, int c, int z, int y, int x) const {
-        // a NaN enters the network with its sign bit clear (x86 code hands over 0/0 as -NaN): the packed 16-bit ReLU of the
-        // streaming kernels (Vec4::store_relu) keeps +NaN and would turn -NaN into 0, where torch's clamp_min keeps either
-        const float v = p[b * sn + c * sc + z * st + y * sh + x * sw];
-        return v != v ? __builtin_nanf("") : v;
+        return p[b * sn + c * sc + z * st + y * sh + x * sw];
     }
 };
 struct SrcU8 {
@@ -83,8 +80,7 @@ struct SrcU8 {
     __device__ float operator()(long long b, int c, int z, int y, int x) const {
         // (float(u8) - mean) / std : the callers' x.sub(mean).div(std) on float32 (af_realtime.py:83)
         float v = (float)p[(((b * t + z) * h + y) * w + x) * 3 + c];
-        const float r = (v - mean[c]) / stdv[c];
-        return r != r ? __builtin_nanf("") : r;           // std = 0 on a pixel equal to the mean: 0/0 (sign: see SrcF32)
+        return (v - mean[c]) / stdv[c];
     }
 };
 

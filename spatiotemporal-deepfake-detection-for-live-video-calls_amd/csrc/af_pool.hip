@@ -43,7 +43,7 @@ __global__ void maxpool_kernel(const PoolArgs a) {
 #pragma unroll
                 for (int i = 0; i < V; ++i) {
                     float v = Elem<DT>::to_f32(e[i]);
-                    best[i] = (v > best[i] || v != v) ? v : best[i];      // NaN propagates like ATen
+                    best[i] = max_nan(best[i], v);                        // NaN propagates like ATen
                 }
             }
         }
