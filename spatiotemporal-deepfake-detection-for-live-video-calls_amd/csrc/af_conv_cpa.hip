@@ -19,8 +19,9 @@
 // late would drain the residual DMA issued before them, so waves 0-3 issue (and wait for) the images and the trunk stores,
 // waves 4-7 the weights.
 //
-// MEASURED (round 3, B = 16, bf16, one box): 0.57 ms against 0.25 + 0.19 ms for the two launches it replaces - the engine keeps
-// the two launches unless AF_FUSE_CPA=1.  With parts switched off (timing builds): no c conv / epilogue 0.39 ms, no a taps
+// MEASURED (round 3, B = 16, bf16, one box): 0.57 ms against 0.25 + 0.19 ms for the two launches it replaces; 0.46 ms once ReLU
+// and the pair max were single v_maximum3_f32 instructions - a tie end to end, so the engine keeps the two launches unless
+// AF_FUSE_CPA=1.  The first measurement:  With parts switched off (timing builds): no c conv / epilogue 0.39 ms, no a taps
 // 0.51, neither and no fetches 0.32 (the barrier / DMA-latency skeleton alone is slower than the 0.27 ms the traffic would take
 // at conv_ca's rate); weight or residual DMA lanes out of range -0.02 / -0.03 ms (not ingest-bound).  A stage here has 50 KB
 // of HBM traffic against conv_ca's 80 KB but more instructions (SQ counters: 523 vector + 263 scalar per wave and stage against
