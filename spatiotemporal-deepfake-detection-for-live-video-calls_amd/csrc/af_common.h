@@ -223,12 +223,26 @@ template <> struct Vec4<AF_BF16> {
         v[0] = relu_f(v[0]); v[1] = relu_f(v[1]); v[2] = relu_f(v[2]); v[3] = relu_f(v[3]);
         store(p, v);
     }
+    static __device__ __forceinline__ unsigned __attribute__((ext_vector_type(2))) pack_relu(f32x4 v) {
+        b4 o; o[0] = (__bf16)relu_f(v[0]); o[1] = (__bf16)relu_f(v[1]); o[2] = (__bf16)relu_f(v[2]); o[3] = (__bf16)relu_f(v[3]);
+        return __builtin_bit_cast(unsigned __attribute__((ext_vector_type(2))), o);
+    }
     static __device__ __forceinline__ f32x4 load(const void* p) {
         b4 i = *reinterpret_cast<const b4*>(p);
         f32x4 o; o[0] = (float)i[0]; o[1] = (float)i[1]; o[2] = (float)i[2]; o[3] = (float)i[3];
         return o;
     }
 };
+// Two MFMA accumulator tiles (lane = 4 consecutive channels of position frow, k-group fg) -> 16 contiguous bytes per lane
+// without LDS: v_permlane16_swap_b32 (gfx950) exchanges the odd 16-lane rows of its first operand with the even rows of the second,
+// so after swapping the packed halves of tile A and tile B a lane holds 8 consecutive channels: fg = 0 / 2: A's channels
+// 0..7 / 8..15, fg = 1 / 3: B's.  (8-byte stores of 32-byte row segments cost the texture path ~3x their share)
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u32x4 swap_pair16(u32x2 a, u32x2 b) {
+    const u32x2 r0 = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
+    const u32x2 r1 = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
+    return u32x4{r0[0], r1[0], r0[1], r1[1]};
+}
 template <> struct Vec4<AF_F16> {
     typedef _Float16 h4 __attribute__((ext_vector_type(4)));
     static __device__ __forceinline__ void store(void* p, f32x4 v) {
@@ -238,6 +252,10 @@ template <> struct Vec4<AF_F16> {
     static __device__ __forceinline__ void store_relu(void* p, f32x4 v) {
         v[0] = relu_f(v[0]); v[1] = relu_f(v[1]); v[2] = relu_f(v[2]); v[3] = relu_f(v[3]);
         store(p, v);
+    }
+    static __device__ __forceinline__ unsigned __attribute__((ext_vector_type(2))) pack_relu(f32x4 v) {
+        h4 o; o[0] = (_Float16)relu_f(v[0]); o[1] = (_Float16)relu_f(v[1]); o[2] = (_Float16)relu_f(v[2]); o[3] = (_Float16)relu_f(v[3]);
+        return __builtin_bit_cast(unsigned __attribute__((ext_vector_type(2))), o);
     }
     static __device__ __forceinline__ f32x4 load(const void* p) {
         h4 i = *reinterpret_cast<const h4*>(p);

@@ -298,20 +298,27 @@ __global__ __launch_bounds__(512, 2) void conv_ca_kernel(const CAArgs a) {
         }
         if (!last) { ++c_kc; continue; }
 
-        // ---- tile finished: BN + ReLU + the one rounding, 8 bytes per lane straight from the accumulators (a 32-KB tile of
-        // a 320-KB tile's traffic: not worth an LDS transposition)
+        // ---- tile finished: BN + ReLU + the one rounding; two channel tiles trade halves between lane rows (v_permlane16_swap), so a
+        // lane stores 16 contiguous bytes (8 channels) and a wave instruction 64-byte row segments - no LDS transposition
 #pragma unroll
         for (int j = 0; j < TM; ++j) {
             const int r = wm * 32 + j * 16 + frow;                   // tile row = t * P + p
             const int t = r / P, p = r - t * P;
             const long long pos = ((long long)n * a.T + t) * a.HW + hw0 + p;
 #pragma unroll
-            for (int i = 0; i < TN; ++i) {
-                const f32x4 sc = *reinterpret_cast<const f32x4*>(bnp + 2 * a.C + i * 16 + fg * 4);
-                const f32x4 sf = *reinterpret_cast<const f32x4*>(bnp + 2 * a.C + 64 + i * 16 + fg * 4);
-                f32x4 v = acc[i][j] * sc + sf;
-                if (hw0 + p < a.HW) Vec4<DT>::store_relu(a.outa + (pos * 64 + i * 16 + fg * 4) * 2, v);
-                acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int ip = 0; ip < TN / 2; ++ip) {
+                u32x2 half[2];
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int i = 2 * ip + k;
+                    const f32x4 sc = *reinterpret_cast<const f32x4*>(bnp + 2 * a.C + i * 16 + fg * 4);
+                    const f32x4 sf = *reinterpret_cast<const f32x4*>(bnp + 2 * a.C + 64 + i * 16 + fg * 4);
+                    half[k] = Vec4<DT>::pack_relu(acc[i][j] * sc + sf);
+                    acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                const u32x4 o = swap_pair16(half[0], half[1]);
+                const int ch = (2 * ip + (fg & 1)) * 16 + (fg >> 1) * 8;
+                if (hw0 + p < a.HW) *reinterpret_cast<u32x4*>(a.outa + (pos * 64 + ch) * 2) = o;
             }
         }
         c_kc = 0; c_tile += gridDim.x;

@@ -315,19 +315,26 @@ __global__ __launch_bounds__(512) void conv_cpa_kernel(const CPAArgs a) {
         }
         if (!last) { ++c_kc; continue; }
 
-        // ---- tile finished: BN + ReLU + the one rounding, 8 bytes per lane straight from the accumulators
+        // ---- tile finished: BN + ReLU + the one rounding; pairs of channel tiles trade halves between lane rows (swap_pair16): a
+        // lane stores 16 contiguous bytes, a wave instruction 64-byte row segments
 #pragma unroll
         for (int j = 0; j < TM; ++j) {
             const int rho = wm_a * 32 + j * 16 + frow, tp = rho >> 3, p = rho & 7;
             const long long pos = (((long long)n * TO + tp) * a.H + h0 + (p >> 2)) * a.W + w0 + (p & 3);
 #pragma unroll
-            for (int i = 0; i < TN; ++i) {
-                const f32x4 sc = *reinterpret_cast<const f32x4*>(bnp + 2 * a.C + wn * 64 + i * 16 + fg * 4);
-                const f32x4 sf = *reinterpret_cast<const f32x4*>(bnp + 2 * a.C + 128 + wn * 64 + i * 16 + fg * 4);
-                f32x4 v = acc[i][j] * sc + sf;
-                v[0] = relu_f(v[0]); v[1] = relu_f(v[1]); v[2] = relu_f(v[2]); v[3] = relu_f(v[3]);
-                Vec4<DT>::store(a.outa + (pos * 128 + wn * 64 + i * 16 + fg * 4) * 2, v);
-                acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int ip = 0; ip < TN / 2; ++ip) {
+                u32x2 half[2];
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int i = 2 * ip + k;
+                    const f32x4 sc = *reinterpret_cast<const f32x4*>(bnp + 2 * a.C + wn * 64 + i * 16 + fg * 4);
+                    const f32x4 sf = *reinterpret_cast<const f32x4*>(bnp + 2 * a.C + 128 + wn * 64 + i * 16 + fg * 4);
+                    half[k] = Vec4<DT>::pack_relu(acc[i][j] * sc + sf);
+                    acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                const u32x4 o = swap_pair16(half[0], half[1]);
+                const int ch = wn * 64 + (2 * ip + (fg & 1)) * 16 + (fg >> 1) * 8;
+                *reinterpret_cast<u32x4*>(a.outa + (pos * 128 + ch) * 2) = o;
             }
         }
         c_kc = 0; c_tile += gridDim.x;
