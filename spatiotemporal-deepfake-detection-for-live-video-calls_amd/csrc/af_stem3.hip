@@ -190,24 +190,18 @@ __global__ __launch_bounds__(512, 2) void stem3_pool_kernel(const Stem3Args a) {
         auto pool_row = [&](int j, const elem_t* pline, int pstart, int pstep) {
             for (int idx = pstart; idx < a.Wq * 8; idx += pstep) {
                 const int q = idx >> 3, ch = (idx & 7) * 8;
-                float m[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) m[e] = 0.f;
+                // the line holds values that went through ReLU: zero, positive, +inf or NaN.  For those the 16-bit patterns of bf16 and
+                // f16 order like unsigned integers with every NaN (either sign) above +inf, so the max is v_pk_max_u16 - two values per
+                // instruction, no conversion - and a NaN member makes the result NaN like ATen's max_pool; 0 = the pool's padding
+                typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+                u16x8 m = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
                 for (int d = -1; d <= 1; ++d) {
                     const int c = 2 * q + d;
-                    if (c >= 0 && c < a.Wo) {
-                        const uint4 raw = *reinterpret_cast<const uint4*>(pline + c * COUT + ch);
-                        const elem_t* pe = reinterpret_cast<const elem_t*>(&raw);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) m[e] = max_nan(m[e], E::to_f32(pe[e]));
-                    }
+                    if (c >= 0 && c < a.Wo)
+                        m = __builtin_elementwise_max(m, *reinterpret_cast<const u16x8*>(pline + c * COUT + ch));
                 }
-                uint4 o;
-                elem_t* oe = reinterpret_cast<elem_t*>(&o);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) oe[e] = E::from_f32(m[e]);
-                *reinterpret_cast<uint4*>(a.out + ((((long long)n * a.To + to) * a.Hq + j) * a.Wq + q) * (a.out_ld * 2) + ch * 2) = o;
+                *reinterpret_cast<u16x8*>(a.out + ((((long long)n * a.To + to) * a.Hq + j) * a.Wq + q) * (a.out_ld * 2) + ch * 2) = m;
             }
         };
 

@@ -151,24 +151,16 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const StemPoolArgs a)
             // horizontal 3-max, stride 2: pooled col q <- conv cols 2q-1, 2q, 2q+1; 8 channels (16 B) per thread
             for (int idx = tid; idx < (j >= j_begin ? a.Wq * 8 : 0); idx += 512) {
                 const int q = idx >> 3, ch = (idx & 7) * 8;
-                float m[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) m[e] = 0.f;
+                // post-ReLU 16-bit patterns order like unsigned integers, NaN (either sign) on top: v_pk_max_u16 (as in af_stem3.hip)
+                typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+                u16x8 m = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
                 for (int d = -1; d <= 1; ++d) {
                     const int c = 2 * q + d;
-                    if (c >= 0 && c < a.Wo) {
-                        const uint4 raw = *reinterpret_cast<const uint4*>(line + c * COUT + ch);
-                        const elem_t* pe = reinterpret_cast<const elem_t*>(&raw);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) m[e] = max_nan(m[e], E::to_f32(pe[e]));
-                    }
+                    if (c >= 0 && c < a.Wo)
+                        m = __builtin_elementwise_max(m, *reinterpret_cast<const u16x8*>(line + c * COUT + ch));
                 }
-                uint4 o;
-                elem_t* oe = reinterpret_cast<elem_t*>(&o);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) oe[e] = E::from_f32(m[e]);
-                *reinterpret_cast<uint4*>(a.out + ((((long long)n * a.To + to) * a.Hq + j) * a.Wq + q) * (COUT * 2) + ch * 2) = o;
+                *reinterpret_cast<u16x8*>(a.out + ((((long long)n * a.To + to) * a.Hq + j) * a.Wq + q) * (COUT * 2) + ch * 2) = m;
             }
             __syncthreads();                                   // line may be overwritten by the next row pair
         }
