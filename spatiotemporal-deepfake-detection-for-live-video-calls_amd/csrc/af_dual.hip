@@ -272,9 +272,17 @@ __global__ __launch_bounds__(256) void dual_head_kernel(const float* z, const fl
     const float* W1t = w + 2 * n; const float* b1 = W1t + (long long)n * hidden; const float* w2 = b1 + hidden;
     float part = 0.f;
     for (int j = tid; j < hidden; j += 256) {
-        float acc = b1[j];
-        for (int k = 0; k < n; ++k) acc = fmaf(x[k], W1t[(long long)k * hidden + j], acc);
-        part = fmaf(gelu_erf(acc), w2[j], part);
+        // eight independent partial sums (k mod 8): one dependent chain of n loads + FMAs took 170 us for 16 clips
+        float acc[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc[u] = 0.f;
+        int k = 0;
+        for (; k + 8 <= n; k += 8)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[u] = fmaf(x[k + u], W1t[(long long)(k + u) * hidden + j], acc[u]);
+        for (; k < n; ++k) acc[0] = fmaf(x[k], W1t[(long long)k * hidden + j], acc[0]);
+        const float sum = b1[j] + (((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7])));
+        part = fmaf(gelu_erf(sum), w2[j], part);
     }
     red[tid] = part;
     __syncthreads();
@@ -310,9 +318,15 @@ __global__ __launch_bounds__(256) void masked_mean_proj_kernel(const float* v, i
     }
     __syncthreads();
     for (int j = tid; j < d; j += 256) {
-        float acc = 0.f;
-        for (int k = 0; k < vis; ++k) acc = fmaf(sm[k], wt[(long long)k * d + j], acc);
-        z[(long long)clip * z_ld + j] = acc;
+        float acc[8];                                   // eight independent partial sums (k mod 8), as in dual_head_kernel
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc[u] = 0.f;
+        int k = 0;
+        for (; k + 8 <= vis; k += 8)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[u] = fmaf(sm[k + u], wt[(long long)(k + u) * d + j], acc[u]);
+        for (; k < vis; ++k) acc[0] = fmaf(sm[k], wt[(long long)k * d + j], acc[0]);
+        z[(long long)clip * z_ld + j] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
     }
 }
 

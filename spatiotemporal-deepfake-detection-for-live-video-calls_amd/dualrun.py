@@ -353,6 +353,7 @@ class DualEncoderRGB(nn.Module):
         self.use_dat, self.domain_head, self.quality_head = False, None, None
         self._packed = None
         self._pe = {}
+        self._mask_checked = None              # (data_ptr, version, shape, device) of the last key_padding_mask that passed validation
 
     def _signature(self):
         first = next(self.parameters())
@@ -407,12 +408,19 @@ class DualEncoderRGB(nn.Module):
                 raise ValueError("key_padding_mask must be a (B,T) bool tensor (True = padding)")
             valid = ~key_padding_mask.to(dev)
             lengths = valid.sum(dim=1).to(torch.int32)
-            prefix = torch.arange(T, device=dev).expand(B, T) < lengths.view(-1, 1)
-            if not bool((prefix == valid).all()):
-                raise ValueError("key_padding_mask must mark a suffix of every clip as padding (lengths_to_mask form)")
-            if bool((lengths == 0).any()):
-                raise ValueError("a clip without any valid frame: upstream's softmax over an all-masked row is NaN; "
-                                 "build the mask with lengths_to_mask, which keeps frame 0")
+            # the two checks read a flag back from the device, i.e. wait for everything enqueued before (a whole AltFreezing forward
+            # in the two-stream model): a mask tensor that passed them is not checked again until it is modified
+            # (an inference-mode tensor has no version counter: always checked)
+            key = None if key_padding_mask.is_inference() else (key_padding_mask.data_ptr(), key_padding_mask._version,
+                                                                tuple(key_padding_mask.shape), str(key_padding_mask.device))
+            if key is None or key != self._mask_checked:
+                prefix = torch.arange(T, device=dev).expand(B, T) < lengths.view(-1, 1)
+                if not bool((prefix == valid).all()):
+                    raise ValueError("key_padding_mask must mark a suffix of every clip as padding (lengths_to_mask form)")
+                if bool((lengths == 0).any()):
+                    raise ValueError("a clip without any valid frame: upstream's softmax over an all-masked row is NaN; "
+                                     "build the mask with lengths_to_mask, which keeps frame 0")
+                self._mask_checked = key
             lengths = lengths.contiguous()
         if not self.rgb_from_features:
             bb = self.rgb_backbone[0]
