@@ -354,6 +354,7 @@ class DualEncoderRGB(nn.Module):
         self._packed = None
         self._pe = {}
         self._mask_checked = None              # (data_ptr, version, shape, device) of the last key_padding_mask that passed validation
+        self._side = None                      # side stream of the two-stream form (rgb_from_features=False)
 
     def _signature(self):
         first = next(self.parameters())
@@ -385,7 +386,7 @@ class DualEncoderRGB(nn.Module):
         return branches, head, wpt
 
     def forward(self, A, L, V=None, key_padding_mask=None, return_weights: bool = False, return_seq: bool = False,
-                return_scores: bool = False):
+                return_scores: bool = False, return_rgb: bool = False):
         from ._lib import check, lib
         if return_weights or return_seq:
             raise NotImplementedError("return_weights / return_seq are training-time outputs")
@@ -422,41 +423,63 @@ class DualEncoderRGB(nn.Module):
                                      "build the mask with lengths_to_mask, which keeps frame 0")
                 self._mask_checked = key
             lengths = lengths.contiguous()
+        clips = None
         if not self.rgb_from_features:
             bb = self.rgb_backbone[0]
-            if bb is None or V.dtype != torch.uint8 or V.dim() != 5:
+            if bb is None or V.dtype != torch.uint8 or V.dim() != 5 or V.shape[0] != B:
                 raise ValueError("rgb_from_features=False needs rgb_backbone (an af_mi355x I3D8x8 / Classifier) and uint8 clips (B,T,H,W,3)")
-            net = getattr(bb, "network", bb)
-            V = net.forward_clips_u8(V, return_pooled=True)["pooled"].view(B, 1, -1)     # one window per sample
-        if V.dim() != 3 or V.shape[0] != B or V.shape[2] != self.vis_dim or V.shape[1] not in (1, T):
+            clips, V = V, None
+        elif V.dim() != 3 or V.shape[0] != B or V.shape[2] != self.vis_dim or V.shape[1] not in (1, T):
             raise ValueError("V must be (B, T or 1, %d) features" % self.vis_dim)
+        if return_rgb and clips is None:
+            raise ValueError("return_rgb needs rgb_from_features=False (the module then runs the RGB backbone itself)")
         if B == 0:
             return A.new_zeros((0,), dtype=torch.float32)
+        rgb = None
         with torch.cuda.device(dev):
             branches, head, wpt = self._pack(dev)
             if T not in self._pe or self._pe[T].device != dev:
                 self._pe[T] = sinusoid_table(T, sp.d_model).to(dev)
-            st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            cur = torch.cuda.current_stream(dev)
             D = sp.d_model
             z = torch.empty((B, 3 * D), dtype=torch.float32, device=dev)
             logits = torch.empty((B,), dtype=torch.float32, device=dev)
             scores = torch.empty((B,), dtype=torch.float32, device=dev) if return_scores else None
             xs = [x.to(torch.float32).contiguous() for x in (A, L)]
-            Vf = V.to(torch.float32).contiguous()
             xp = (C.c_void_p * 2)(*[x.data_ptr() for x in xs])
             wp = (C.c_void_p * 2)(*[branches[name].data_ptr() for name, _ in sp.branches()])
             dins = (C.c_int * 2)(*[din for _, din in sp.branches()])
             lp = None if lengths is None else C.c_void_p(lengths.data_ptr())
-            check(lib.af_dual_branch_encoders(2, xp, wp, dins, lp, C.c_void_p(self._pe[T].data_ptr()), B, T, D, sp.depth, sp.heads,
-                                              sp.ff, C.c_float(sp.pool_tau), C.c_void_p(z.data_ptr()), 3 * D, st),
-                  "af_dual_branch_encoders")
+
+            def branch_encoders(stream):
+                check(lib.af_dual_branch_encoders(2, xp, wp, dins, lp, C.c_void_p(self._pe[T].data_ptr()), B, T, D, sp.depth, sp.heads,
+                                                  sp.ff, C.c_float(sp.pool_tau), C.c_void_p(z.data_ptr()), 3 * D,
+                                                  C.c_void_p(stream.cuda_stream)), "af_dual_branch_encoders")
+
+            if clips is None:
+                branch_encoders(cur)
+            else:
+                # the AU / landmark encoders do not depend on the RGB stream: their 2 x B workgroups (0.5 ms on 2 x B of the 256 CUs)
+                # run on a side stream beside the backbone's forward and meet it in front of the projection of the pooled feature
+                if self._side is None or self._side.device != dev:
+                    self._side = torch.cuda.Stream(dev)
+                side = self._side
+                side.wait_stream(cur)
+                for t_ in xs + [z] + ([lengths] if lengths is not None else []):
+                    t_.record_stream(side)
+                branch_encoders(side)
+                net = getattr(self.rgb_backbone[0], "network", self.rgb_backbone[0])
+                rgb = net.forward_clips_u8(clips, return_pooled=True)
+                V = rgb["pooled"].view(B, 1, -1)                                      # one window per sample
+                cur.wait_stream(side)
+            st = C.c_void_p(cur.cuda_stream)
+            Vf = V.to(torch.float32).contiguous()
             check(lib.af_masked_mean_proj(C.c_void_p(Vf.data_ptr()), B, Vf.shape[1], self.vis_dim, lp, T, C.c_void_p(wpt.data_ptr()), D,
                                           C.c_void_p(z.data_ptr() + 4 * 2 * D), 3 * D, st), "af_masked_mean_proj")
             check(lib.af_mlp_head(C.c_void_p(z.data_ptr()), C.c_void_p(head.data_ptr()), B, 3 * D, 2 * D, C.c_void_p(logits.data_ptr()),
                                   None if scores is None else C.c_void_p(scores.data_ptr()), st), "af_mlp_head")
-        if return_scores:
-            return logits, scores
-        return logits
+        out = (logits, scores) if return_scores else logits
+        return (out, rgb) if return_rgb else out
 
 
 class GatedMoE(nn.Module):

@@ -162,6 +162,10 @@ def test_two_stream_model_as_one_unit(dual_rgb):
         with torch.inference_mode():
             rgb = clf.network.forward_clips_u8(u8.cuda(), return_scores=True, return_pooled=True)
             z_dual = net(A.cuda(), L.cuda(), u8.cuda(), key_padding_mask=mask)
+            # return_rgb: the same call also hands back the backbone's own outputs (one forward for both streams)
+            z_dual2, rgb2 = net(A.cuda(), L.cuda(), u8.cuda(), key_padding_mask=mask, return_rgb=True)
+            assert torch.equal(z_dual2, z_dual) and torch.equal(rgb2["final_output"], rgb["final_output"])
+            assert torch.equal(rgb2["pooled"], rgb["pooled"])
             moe = dualrun.GatedMoE().cuda().eval()
             z, gate = moe(rgb["final_output"], z_dual.view(B, 1))
     finally:
