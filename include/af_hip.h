@@ -351,6 +351,17 @@ typedef struct af_align_frame {
 int af_warp_affine_clip_u8(const void* crops, const af_align_frame* frames, int n_frames, int canvas_h, int canvas_w,
                            const double* tfm, int size, void* out, void* stream);
 
+/* Host-side staging for the aligner (no device work): copies n rectangles of uint8 rows (the part of each crop the warp can
+ * sample) into one staging buffer, one memcpy per row.  dst_offset / rows / row_bytes describe the packed destination,
+ * src_pitch the source's row pitch in bytes.  (ABI 3) */
+typedef struct af_stage_rect {
+    const void* src;
+    int64_t dst_offset;
+    int64_t src_pitch;
+    int32_t rows, row_bytes;
+} af_stage_rect;
+int af_stage_rows_u8(void* dst, const af_stage_rect* rects, int n);
+
 /* ---- whole-forward op list ------------------------------------------------------------ */
 
 enum af_op_kind { AF_OP_STEM = 0, AF_OP_CONV = 1, AF_OP_MAXPOOL = 2, AF_OP_HEAD = 3,

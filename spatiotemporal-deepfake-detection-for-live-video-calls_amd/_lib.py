@@ -22,6 +22,10 @@ class ConvDesc(C.Structure):
         "to", "ho", "wo", "relu", "dtype", "tpool")]
 
 
+class StageRect(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst_offset", C.c_int64), ("src_pitch", C.c_int64), ("rows", C.c_int32), ("row_bytes", C.c_int32)]
+
+
 class AlignFrame(C.Structure):
     _fields_ = [("offset", C.c_int64), ("ih", C.c_int32), ("iw", C.c_int32), ("x", C.c_int32), ("y", C.c_int32)]
 
@@ -87,6 +91,7 @@ ABI = {
     "af_conv3d_dual_bn_act": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_void_p, C.POINTER(ConvDesc)] + [C.c_void_p] * 5
                               + [C.c_int, C.c_void_p]),
     "af_conv_ca_fusable": (C.c_int, [C.POINTER(ConvDesc)] * 3),
+    "af_stage_rows_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "af_conv_cpa_fusable": (C.c_int, [C.POINTER(ConvDesc)] * 2 + [C.c_int]),
     "af_conv3d_cpa_bn_act": (C.c_int, [C.POINTER(ConvDesc)] + [C.c_void_p] * 6 + [C.c_int, C.POINTER(ConvDesc)] + [C.c_void_p] * 5),
     "af_conv3d_ca_bn_act": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_void_p, C.POINTER(ConvDesc)] + [C.c_void_p] * 6

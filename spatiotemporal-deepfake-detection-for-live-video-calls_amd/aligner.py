@@ -95,6 +95,10 @@ class _StagingRing:
         return k
 
 
+# also cut the COLUMNS the warp cannot sample (rows are always cut)?  Measured on one box with the C staging copy: rows only 1 448
+# clips/s host-inclusive, rows + columns 1 020-1 100 - 22 % fewer bytes, but 8 000 short strided memcpys per clip run far below the
+# rate of 32 long ones.  Off; AF_ALIGN_COLS=1 switches it on for A/B runs.
+_CLIP_COLUMNS = os.environ.get("AF_ALIGN_COLS", "0") == "1"
 _COPY_THREADS = 2          # measured on the MI355X host: 1 thread 45 GB/s, 2 threads 72 GB/s, 4+ slower (memory-bound copies)
 _copy_pool = None
 
@@ -168,10 +172,14 @@ class FasterCropAlignXRay:
             if im.ndim == 3 and (x < 0 or y < 0 or x + im.shape[1] > w or y + im.shape[0] > h):
                 # numpy refuses new_image[y:y+ih, x:x+iw] = image for a crop that sticks out of the canvas
                 raise ValueError("aligner: frame %d (%dx%d at %d,%d) does not fit the %dx%d canvas" % (i, im.shape[1], im.shape[0], x, y, w, h))
-        images, diff = self._clip_rect(images, diff, tfm)
+        shapes = []
+        for im in images:
+            if not (isinstance(im, np.ndarray) and im.dtype == np.uint8 and im.ndim == 3 and im.shape[2] == 3):
+                raise AssertionError("aligner: images must be HxWx3 uint8 numpy arrays")
+        images, shapes, diff = self._clip_rect(images, diff, tfm)
         with torch.cuda.device(dev):
             crops, offs, slot = self.stage_crops_ring(images, dev)
-            self.launch_warps(crops, offs, [im.shape for im in images], diff, h, w, tfm, out)
+            self.launch_warps(crops, offs, shapes, diff, h, w, tfm, out)
             ev = torch.cuda.Event()
             ev.record()
             self._ring.done[slot] = ev
@@ -179,13 +187,12 @@ class FasterCropAlignXRay:
 
     def _clip_rect(self, images: Sequence[np.ndarray], diff: np.ndarray, tfm: np.ndarray):
         """the rectangle of the canvas the size x size destination can sample (bilinear taps, fixed-point rounding: 3 pixels of
-        margin) -> per frame the part of the crop inside it (a view, no copy) and the paste offset moved accordingly.  (Round 2
-        cut rows only - a contiguous view; the columns halve the bytes once more and the strided copy into the pinned slot costs
-        less than the PCIe time they would have taken.)"""
+        margin) -> per frame the part of the crop inside it (a rows x bytes view, no copy), its (h, w, 3) shape and the paste offset
+        moved accordingly.  Rows are always cut (a contiguous view); columns only with AF_ALIGN_COLS=1 (see _CLIP_COLUMNS)."""
         m = np.asarray(tfm, dtype=np.float64).reshape(2, 3)
         det = m[0, 0] * m[1, 1] - m[0, 1] * m[1, 0]
         if not np.isfinite(det) or abs(det) < 1e-12:
-            return images, diff                              # singular map: OpenCV's D = 0 path samples around one point; keep everything
+            return images, [im.shape for im in images], diff # singular map: OpenCV's D = 0 path samples around one point; keep everything
         s = float(self.image_size - 1)
         corners = np.array([[0.0, 0.0], [s, 0.0], [0.0, s], [s, s]])
         # dst = M [x y 1]^T  ->  src = M^-1 (dst - t)
@@ -193,26 +200,35 @@ class FasterCropAlignXRay:
         xs = (m[1, 1] * dx - m[0, 1] * dy) / det
         ys = (-m[1, 0] * dx + m[0, 0] * dy) / det
         if not (np.isfinite(xs).all() and np.isfinite(ys).all()):
-            return images, diff
+            return images, [im.shape for im in images], diff
         ylo, yhi = int(np.floor(ys.min())) - 3, int(np.ceil(ys.max())) + 4
         xlo, xhi = int(np.floor(xs.min())) - 3, int(np.ceil(xs.max())) + 4
-        out_images, out_diff = [], np.array(diff, dtype=np.int64, copy=True)
+        out_images, shapes, out_diff = [], [], np.array(diff, dtype=np.int64, copy=True)
         for i, im in enumerate(images):
             x0, y0 = int(out_diff[i][0]), int(out_diff[i][1])
             r0, r1 = max(0, ylo - y0), min(im.shape[0], yhi - y0)
             c0, c1 = max(0, xlo - x0), min(im.shape[1], xhi - x0)
+            if not _CLIP_COLUMNS:
+                c0, c1 = 0, im.shape[1]
             if r1 <= r0 or c1 <= c0:                         # the warp never reaches this crop: one pixel keeps the frame table valid
                 r0, r1, c0, c1 = 0, 1, 0, 1
-            out_images.append(im[r0:r1, c0:c1])
+            rows = im[r0:r1]
+            if rows.flags.c_contiguous:
+                # rows x bytes: the column cut of a (rows, W * 3) view copies as one memcpy per row (the (h, w, 3) view of the
+                # same pixels went element by element: 5 GB/s instead of 45)
+                out_images.append(rows.reshape(r1 - r0, im.shape[1] * 3)[:, c0 * 3:c1 * 3])
+            else:
+                out_images.append(np.ascontiguousarray(rows[:, c0:c1]).reshape(r1 - r0, (c1 - c0) * 3))
+            shapes.append((r1 - r0, c1 - c0, 3))
             out_diff[i][0], out_diff[i][1] = x0 + c0, y0 + r0
-        return out_images, out_diff
+        return out_images, shapes, out_diff
 
     @staticmethod
     def _layout(images: Sequence[np.ndarray]):
         offs, total = [], 0
         for im in images:
-            if not (isinstance(im, np.ndarray) and im.dtype == np.uint8 and im.ndim == 3 and im.shape[2] == 3):
-                raise AssertionError("aligner: images must be HxWx3 uint8 numpy arrays")
+            if not (isinstance(im, np.ndarray) and im.dtype == np.uint8 and (im.ndim == 2 or (im.ndim == 3 and im.shape[2] == 3))):
+                raise AssertionError("aligner: images must be HxWx3 uint8 numpy arrays (or their rows x bytes views)")
             offs.append(total)
             total += (im.size + 15) // 16 * 16
         return offs, total
@@ -220,19 +236,36 @@ class FasterCropAlignXRay:
     def stage_crops_ring(self, images: Sequence[np.ndarray], dev):
         """crops -> a pinned ring slot (copy threads; numpy releases the GIL for these copies) -> one asynchronous H2D copy
         into the slot's device twin; returns (device bytes, per-frame byte offsets, slot)"""
+        from . import _lib
         offs, total = self._layout(images)
         k = self._ring.acquire(total, dev)
-        hv = self._ring.host[k].numpy()
-        pairs = [(hv[o:o + im.size], im) for im, o in zip(images, offs)]
+        host = self._ring.host[k]
+        # one C call per copy thread (af_stage_rows_u8: a memcpy per row; ctypes releases the GIL): numpy copies a column-cut view
+        # with ~100 ns of iterator overhead per row - 8 000 rows per clip, half of the whole call
+        rects = (_lib.StageRect * len(images))()
+        for i, (im, o) in enumerate(zip(images, offs)):
+            if im.ndim == 3:
+                im = im.reshape(im.shape[0], im.shape[1] * 3) if im.flags.c_contiguous else np.ascontiguousarray(im).reshape(im.shape[0], -1)
+            if im.strides[1] != 1:
+                im = np.ascontiguousarray(im)
+            rects[i] = _lib.StageRect(im.ctypes.data, o, im.strides[0] if im.shape[0] > 1 else im.shape[1], im.shape[0], im.shape[1])
+        keep = images                                               # (the arrays stay alive until the copies below have returned)
+        base = host.data_ptr()
         # (staging in four chunks, each crossing PCIe while the next is copied, was tried: the extra pool round trips and small
         #  copies cost more than the overlap gained - host-inclusive 1 780 -> 860 clips/s)
-        nt = min(_COPY_THREADS, len(pairs))
+        nt = min(_COPY_THREADS, len(images))
         if nt > 1 and total >= (1 << 20):
-            list(_pool().map(_copy_group, [pairs[i::nt] for i in range(nt)]))
+            n = len(images)
+            cuts = [n * t // nt for t in range(nt + 1)]
+            def part(t):
+                _lib.check(_lib.lib.af_stage_rows_u8(C.c_void_p(base), C.byref(rects, cuts[t] * C.sizeof(_lib.StageRect)), cuts[t + 1] - cuts[t]),
+                           "stage_rows_u8")
+            list(_pool().map(part, range(nt)))
         else:
-            _copy_group(pairs)
+            _lib.check(_lib.lib.af_stage_rows_u8(C.c_void_p(base), rects, len(images)), "stage_rows_u8")
+        del keep
         d = self._ring.dev[k]
-        d[:total].copy_(self._ring.host[k][:total], non_blocking=True)
+        d[:total].copy_(host[:total], non_blocking=True)
         return d, offs, k
 
     @staticmethod
