@@ -375,3 +375,27 @@ def test_hand_counted_vmcnt_kernels_have_no_spills_and_no_early_use_of_uncounted
                     f, sorted(hit), i + 1, t, j + 1, u)
     assert n_counted >= 10, n_counted                              # ... including the kernels with counted waits
     assert n_kernels >= 40 and n_loads >= 8, (n_kernels, n_loads)   # the lint saw the kernels / loads it is meant for
+
+
+def test_stage_rows_host_helper_matches_numpy():
+    """af_stage_rows_u8 is host code (the aligner's copy of the sampled crop rows into its pinned staging buffer): contiguous and
+    strided rectangles against numpy, a refused rectangle (pitch smaller than the row)."""
+    import ctypes as C
+    import numpy as np
+    from af_mi355x import _lib
+    rng = np.random.default_rng(5)
+    imgs = [rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8) for h, w in ((37, 53), (64, 64), (5, 301))]
+    views = [imgs[0].reshape(37, -1), imgs[1][10:50].reshape(40, -1)[:, 12:150], imgs[2].reshape(5, -1)[:, 3:900]]
+    offs, total = [], 0
+    for v in views:
+        offs.append(total)
+        total += (v.size + 15) // 16 * 16
+    dst = np.full(total, 7, dtype=np.uint8)
+    rects = (_lib.StageRect * len(views))()
+    for i, (v, o) in enumerate(zip(views, offs)):
+        rects[i] = _lib.StageRect(v.ctypes.data, o, v.strides[0], v.shape[0], v.shape[1])
+    _lib.check(_lib.lib.af_stage_rows_u8(C.c_void_p(dst.ctypes.data), rects, len(views)), "stage_rows_u8")
+    for v, o in zip(views, offs):
+        assert np.array_equal(dst[o:o + v.size].reshape(v.shape), v)
+    bad = (_lib.StageRect * 1)(_lib.StageRect(views[1].ctypes.data, 0, 10, 4, 138))
+    assert _lib.lib.af_stage_rows_u8(C.c_void_p(dst.ctypes.data), bad, 1) != 0
