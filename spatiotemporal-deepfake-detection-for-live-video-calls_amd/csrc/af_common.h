@@ -17,6 +17,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // voff is outside the descriptor's 2 GiB window (kOutOfRange) gets zeros - that is how padding taps, rows beyond M
 // and channel tails are filled.  hipcc does not count this load: every wait on it is an explicit s_waitcnt vmcnt(N).
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr unsigned kOutOfRange = 0x80000000u;
 __device__ __forceinline__ void blds16(unsigned voff, const i32x4& desc, int soff, unsigned lds_base) {
     unsigned keep;
@@ -74,6 +75,42 @@ __device__ __forceinline__ float max_nan(float m, float x) { return __builtin_el
 __device__ __forceinline__ float min_nan(float m, float x) { return __builtin_elementwise_minimum(m, x); }
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// LDS fragment reads hipcc does NOT count (round 4).  A software-pipelined K loop reads the fragments of half-step h + 1 while
+// half-step h multiplies; when the reads of h were issued in the previous loop iteration and the body has control flow in it
+// (conditional DMA issue), hipcc's wait insertion gives up counting across the back edge and puts s_waitcnt lgkmcnt(0) in front
+// of the first MFMA - behind the reads just issued, i.e. the whole LDS round trip of 8 waves x 11 reads is exposed once per
+// K-step (conv133g, ISA dump of tools/isa_schedule.py).  With the reads as inline asm the kernel waits itself: lgkmcnt counts LDS
+// operations in issue order, so wait_lgkmcnt<N>() = "all but my N youngest reads are back"; the registers then pass through
+// pin_frag (an empty asm with a "+v" operand) so that no consumer can be scheduled above the wait.
+template <int OFF> __device__ __forceinline__ u32x4 lds_read16_uncounted(unsigned addr) {
+    u32x4 r;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF) : "memory");
+    return r;
+}
+template <int N> __device__ __forceinline__ void wait_lgkmcnt() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void pin_frag(u32x4& v) { asm volatile("" : "+v"(v)); }
+// An MFMA as an asm statement, accumulating IN PLACE ("+v"): hipcc's three-address form of the builtin gave every unrolled K-step
+// body its own accumulator registers (an unrolled 9-tap loop of 28 accumulator tiles then spilled ~300 registers), and an asm
+// statement is issued exactly where it is written.  Hazards are the caller's: an accumulate chain on the same tile needs no
+// wait state; anything ELSE that reads or writes the tile behind the last MFMA does (mfma_drain() in front of the epilogue).
+template <int DT> struct MmaAsm;
+template <> struct MmaAsm<AF_BF16> {
+    static __device__ __forceinline__ void run(const u32x4& a, const u32x4& b, f32x4& c) {
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+    }
+};
+template <> struct MmaAsm<AF_F16> {
+    static __device__ __forceinline__ void run(const u32x4& a, const u32x4& b, f32x4& c) {
+        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+    }
+};
+__device__ __forceinline__ void mfma_drain() { asm volatile("s_nop 15\n\ts_nop 7" ::: "memory"); }   // > the 8-pass MFMA's 12 wait states
+// compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{}) (asm immediates need constants)
+template <int I> struct IC { static constexpr int value = I; constexpr operator int() const { return I; } };
+template <int N, int I = 0, class F> __device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) { f(IC<I>{}); static_for<N, I + 1>(f); }
+}
 
 // af_conv133.hip: register-resident-weights 1x3x3 64->64 kernel (s2 `b` convs), 16-bit dtypes
 bool conv133_applies(const af_conv_desc* d, const void* residual, int out_ld);
@@ -155,7 +192,6 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 static inline int dtype_size(int dt) { return dt == AF_F32 ? 4 : 2; }
 static inline bool dtype_ok(int dt) { return dt == AF_F32 || dt == AF_BF16 || dt == AF_F16; }
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 

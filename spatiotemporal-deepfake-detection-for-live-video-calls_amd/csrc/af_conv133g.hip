@@ -20,8 +20,24 @@
 //     tiles per wave); the K loop is software-pipelined by k-halves like the generic kernel's 2-slot variant;
 //   * at B = 16 the 256 frames of s4 are exactly one unit per CU, the 512 half-frames of s3 exactly two rounds.
 #include "af_common.h"
+#include <stdlib.h>
 
 namespace af {
+
+// Diagnostic build (-DAF_STAMPS, tools/stamps_lib.sh; never the shipped library): shader-clock stamps around the phases of a
+// unit, kept in scalar registers and written behind the last output store, to a buffer nothing else reads.
+#ifdef AF_STAMPS
+#define AF_STAMP_DECL unsigned long long stamp_v[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define AF_DBG(bit) (a.dbg & (bit))
+#define AF_STAMP(slot) stamp_v[slot] = (slot) >= 6 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime()
+#define AF_STAMP_FLUSH do { if (a.stamps && lane < 8) a.stamps[((long long)blockIdx.x * 8 + wave) * 8 + lane] = \
+    lane == 0 ? stamp_v[0] : lane == 1 ? stamp_v[1] : lane == 2 ? stamp_v[2] : lane == 3 ? stamp_v[3] : lane == 4 ? stamp_v[4] : lane == 5 ? stamp_v[5] : lane == 6 ? stamp_v[6] : stamp_v[7]; } while (0)
+#else
+#define AF_STAMP_DECL do {} while (0)
+#define AF_DBG(bit) false
+#define AF_STAMP(slot) do {} while (0)
+#define AF_STAMP_FLUSH do {} while (0)
+#endif
 
 struct C133GArgs {
     const char* in;
@@ -43,9 +59,15 @@ struct C133GArgs {
     const float* shift2;
     const char* res;     // [frames][H][W][Cout2] or null
     int Cout2, relu2;
+    int stagger;         // waves 4-7 take the K loop's barrier half an MFMA group late (AF_G_STAGGER=0 for A/B runs)
+#ifdef AF_STAMPS
+    unsigned long long* stamps;   // diagnostic build only (tools/stamps_lib.sh): [unit][wave][8] shader-clock / wall-clock stamps
+    int dbg;                      // timing-only ablations of the K loop (AF_G_DBG; outputs are then garbage, addresses unchanged):
+                                  // 1 no vmcnt wait, 2 no barrier, 4 no weight DMA, 8 no LDS fragment reads, 16 no patch DMA
+#endif
 };
 
-template <int DT, int WN, int WM, int MT, bool FUSEC>
+template <int DT, int WN, int WM, int MT, bool FUSEC, int MAXP, int NSLOT>
 __global__ __launch_bounds__(512, 2) void conv133g_kernel(const C133GArgs a) {
     typedef Elem<DT> E;
     typedef typename E::type OT;
@@ -54,7 +76,7 @@ __global__ __launch_bounds__(512, 2) void conv133g_kernel(const C133GArgs a) {
     constexpr int BN = WN * 64;                        // output channels of the workgroup (= Cout)
     constexpr int RW = BN / 64;                        // weight DMA pieces per wave per stage
     constexpr int WSTAGE = BN * 128;                   // bytes of a weight stage ([BN][64 k])
-    constexpr int MAXP = 9;                            // patch DMA pieces per wave (patch <= 576 rows; one piece per tap)
+    // MAXP: patch DMA pieces per wave (patch rows <= 64 MAXP; one piece per tap, so <= 9: 576 rows)
     constexpr int PROW = 64 + 8;                       // epilogue patch row stride (elements)
 
     extern __shared__ uint4 smem[];
@@ -76,9 +98,8 @@ __global__ __launch_bounds__(512, 2) void conv133g_kernel(const C133GArgs a) {
     const int lrow = tid >> 3, wchunk = (tid & 7) ^ (lrow & 7);
     const long long Kw = 9LL * a.kt * a.Cin;                           // weight row length (elements)
     const i32x4 wdesc = make_desc(a.w);
-    unsigned woff[RW];
-#pragma unroll
-    for (int i = 0; i < RW; ++i) woff[i] = (unsigned)(((lrow + 64 * i) * Kw + wchunk * 8) * 2);
+    const unsigned woff = (unsigned)((lrow * Kw + wchunk * 8) * 2);    // piece i: + 64 i weight rows (added to the scalar offset)
+    const int wpiece_bytes = (int)(64 * Kw * 2);
     // Patch: LDS row j <-> padded pixel q = j - 1 = (r, c) = (q / WP, q % WP) <-> input pixel (h0 - 1 + r, c - 1); rows
     // beyond the band, halo columns and rows outside the image are out-of-range lanes (zeros).  Piece g = rows 8g .. 8g+7.
     const int NP = a.prows >> 3;
@@ -88,27 +109,26 @@ __global__ __launch_bounds__(512, 2) void conv133g_kernel(const C133GArgs a) {
     const int pt = a.kt >> 1, tclip = frame % a.T;
     const int frame_bytes = a.H * a.W * a.Cin * 2;                     // < 2^29 (host-checked)
     const i32x4 xdesc = make_desc(a.in + ((((long long)frame - pt) * a.H + h0 - 1) * a.W) * a.Cin * 2);
-    unsigned poff[MAXP];
-#pragma unroll
-    for (int i = 0; i < MAXP; ++i) {
-        const int q = (wave + 8 * i) * 8 + drow - 1;
-        const int r = (int)(((float)q + 0.5f) * a.inv_wp), c = q - r * WP;
-        const bool ok = q >= 0 && r < a.R + 2 && c >= 1 && c <= a.W && (unsigned)(h0 - 1 + r) < (unsigned)a.H;
-        poff[i] = ok ? (unsigned)(((r * a.W + (c - 1)) * a.Cin) * 2 + pchunk * 16) : kOutOfRange;
-    }
-    auto issue_patch_piece = [&](int buf, int ks, int i) {
-        if (wave + 8 * i < NP) {
-            const int dt = (ks >= a.kslabs) + (ks >= 2 * a.kslabs), cs = ks - dt * a.kslabs;
-            const bool inclip = (unsigned)(tclip + dt - pt) < (unsigned)a.T;
-            blds16(inclip ? poff[i] : kOutOfRange, xdesc, __builtin_amdgcn_readfirstlane(dt * frame_bytes + cs * 128),
-                   __builtin_amdgcn_readfirstlane(lds0 + buf * pbytes + (wave + 8 * i) * 1024));
-        }
-    };
-    // weight stage for K-step (tap, slab ks) into ring slot st, one piece (64 rows) at a time; packed [Cout][kt * 9][Cin]
-    auto issue_w_piece = [&](int st, int tap, int ks, int i) {
+    unsigned poff[MAXP];                               // (filled in behind the first weight DMAs, below)
+    // patch piece i of this wave (rows 8 (wave + 8 i) ..) of K slab (frame offset + channel slab = `soff`) into patch buffer at `bufoff`
+    auto patch_slab_offset = [&](int ks, bool& inclip) {
         const int dt = (ks >= a.kslabs) + (ks >= 2 * a.kslabs), cs = ks - dt * a.kslabs;
-        blds16(woff[i], wdesc, __builtin_amdgcn_readfirstlane(((dt * 9 + tap) * a.Cin + cs * 64) * 2),
-               __builtin_amdgcn_readfirstlane(ring0 + st * WSTAGE + (64 * i + 8 * wave) * 128));
+        inclip = (unsigned)(tclip + dt - pt) < (unsigned)a.T;
+        return __builtin_amdgcn_readfirstlane(dt * frame_bytes + cs * 128);
+    };
+    auto issue_patch_piece = [&](int bufoff, int soff, bool inclip, int i) {
+        if (wave + 8 * i < NP)
+            blds16_m0(inclip ? poff[i] : kOutOfRange, xdesc, soff, __builtin_amdgcn_readfirstlane(lds0 + bufoff + (wave + 8 * i) * 1024));
+    };
+    // weight stage of K-step (tap, slab ks) into the ring slot at byte offset `stoff`, one piece (64 rows) at a time; packed
+    // [Cout][kt * 9][Cin]: offset inside a weight row = w_slab_offset(ks) + tap * Cin * 2
+    auto w_slab_offset = [&](int ks) {
+        const int dt = (ks >= a.kslabs) + (ks >= 2 * a.kslabs), cs = ks - dt * a.kslabs;
+        return __builtin_amdgcn_readfirstlane((dt * 9 * a.Cin + cs * 64) * 2);
+    };
+    const int tap_bytes = a.Cin * 2;
+    auto issue_w_piece = [&](int stoff, int soff, int i) {
+        blds16_m0(woff, wdesc, soff + i * wpiece_bytes, __builtin_amdgcn_readfirstlane(ring0 + stoff + (64 * i + 8 * wave) * 128));
     };
 
     f32x4 acc[NT][MT];
@@ -118,97 +138,174 @@ __global__ __launch_bounds__(512, 2) void conv133g_kernel(const C133GArgs a) {
         for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nslabs = a.kt * a.kslabs;                // K slabs (dt, cs)
-    const int S = 9 * nslabs;
-    // ---- prologue: patches of slab 0 (and 1), weight stages 0 and 1
+    AF_STAMP_DECL;
+    AF_STAMP(0); AF_STAMP(6);
+    // ---- prologue: the first NSLOT weight stages (taps 0 .. NSLOT - 1 of slab 0) are issued before the per-lane patch offsets
+    // are even computed (~100 vector instructions), then the patch of slab 0; slab 1's patch rides on the K-steps of slab 0, one
+    // piece per step, like every later one
+    {
 #pragma unroll
-    for (int i = 0; i < MAXP; ++i) issue_patch_piece(0, 0, i);
+        for (int k = 0; k < NSLOT; ++k)
 #pragma unroll
-    for (int i = 0; i < RW; ++i) issue_w_piece(0, 0, 0, i);
-#pragma unroll
-    for (int i = 0; i < RW; ++i) issue_w_piece(1, 1, 0, i);
-    if (nslabs > 1) {
-#pragma unroll
-        for (int i = 0; i < MAXP; ++i) issue_patch_piece(1, 1, i);
+            for (int i = 0; i < RW; ++i) issue_w_piece(k * WSTAGE, w_slab_offset(0) + k * tap_bytes, i);
     }
 
-    const char* sm = reinterpret_cast<const char*>(smem);
-    const int arow = (wn * 64 + frow) * 128, brow = (wm * MT * 16 + frow) * 128;
-    // fragments of k-half kk of K-step (tap shift `sh`, patch buffer `buf`, ring slot `st`)
-    uint4 a0[NT], b0[MT], a1[NT], b1[MT];
-    auto read_half = [&](uint4 (&af)[NT], uint4 (&bf)[MT], int st, int buf, int sh, int kk) {
-        const char* wsb = sm + 2 * pbytes + st * WSTAGE + arow + ((((kk << 2) + fg) ^ (frow & 7)) << 4);
-        const char* xsb = sm + buf * pbytes + brow + sh * 128 + ((((kk << 2) + fg) ^ ((frow + sh) & 7)) << 4);
 #pragma unroll
-        for (int i = 0; i < NT; ++i) af[i] = *reinterpret_cast<const uint4*>(wsb + i * (16 * 128));
+    for (int i = 0; i < MAXP; ++i) {
+        const int q = (wave + 8 * i) * 8 + drow - 1;
+        const int r = (int)(((float)q + 0.5f) * a.inv_wp), c = q - r * WP;
+        const bool ok = q >= 0 && r < a.R + 2 && c >= 1 && c <= a.W && (unsigned)(h0 - 1 + r) < (unsigned)a.H;
+        poff[i] = ok ? (unsigned)(((r * a.W + (c - 1)) * a.Cin) * 2 + pchunk * 16) : kOutOfRange;
+    }
+    {
+        bool in0;
+        const int ps0 = patch_slab_offset(0, in0);
 #pragma unroll
-        for (int j = 0; j < MT; ++j) bf[j] = *reinterpret_cast<const uint4*>(xsb + j * (16 * 128));
+        for (int i = 0; i < MAXP; ++i) issue_patch_piece(0, ps0, in0, i);
+    }
+    const unsigned arow = ring0 + (wn * 64 + frow) * 128, brow = lds0 + (wm * MT * 16 + frow) * 128;
+    // ---- the K loop: every instruction of it is an asm statement (MFMAs in place, uncounted LDS reads, LDS-DMA, waits), issued
+    // in program order; hipcc allocates the registers and does the address arithmetic.
+    //   * The nine taps of a slab are unrolled: tap, its (dh, dw) row shift, the patch piece that rides on the step and the
+    //     step two ahead are compile-time facts of each body.  (The dynamic cursor + a nine-way branch chain that picked the
+    //     patch piece cost ~200 scalar instructions per 56 MFMAs, which two in-order waves per SIMD could not hide: with every
+    //     memory operation removed the round-3 loop still ran at 0.8 of the MFMA rate.)
+    //   * The fragments of the NEXT half-step are read between the MFMAs of this one, one ds_read_b128 per two MFMAs, so a
+    //     read burst never stands between a barrier and the matrix pipe.
+    //   * LATE waves (4-7, the SIMD partners of 0-3) take the step's one barrier H1 MFMAs into their first group instead of
+    //     behind it: the partners' barrier waits, DMA issue and address arithmetic fall on each other's MFMA stretches
+    //     (MI355X_MICROARCH.md, "two waves that run the same program with one barrier per block").  Same LDS protocol: a wave
+    //     issues - and waits for - its reads of ring slot `stoff` / the previous slab's patch in front of its barrier.
+    u32x4 a0[NT], b0[MT], a1[NT], b1[MT];
+    auto frag_read = [&](u32x4 (&af)[NT], u32x4 (&bf)[MT], unsigned wsb, unsigned xsb, auto idx) {
+        constexpr int r = decltype(idx)::value;
+        if constexpr (r < NT) af[r] = lds_read16_uncounted<r * (16 * 128)>(wsb);
+        else if constexpr (r < NT + MT) bf[r - NT] = lds_read16_uncounted<(r - NT) * (16 * 128)>(xsb);
     };
-    constexpr int NTH = NT * MT;
-
-    wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    // consumer cursor: K-step s = (slab, tap); dh / dw of the tap; the step after it
-    int tap = 0, slab = 0, dh = 0, dw = 0;
-    read_half(a0, b0, 0, 0, 0, 0);
-    for (int s = 0; s + 1 < S; ++s) {
-        const int st = s & 1, buf = slab & 1, sh = dh * WP + dw;
-        // next K-step
-        int ntap = tap + 1, nslab = slab, ndh = dh, ndw = dw + 1;
-        if (ndw == 3) { ndw = 0; ++ndh; }
-        if (ntap == 9) { ntap = 0; ndh = 0; ++nslab; }
-        // K-step s + 2 (the weight stage that refills this slot)
-        int t2 = ntap + 1, s2 = nslab;
-        if (t2 == 9) { t2 = 0; ++s2; }
-        const bool refill = s + 2 < S;
-        // the slab after next: its patch goes where slab - 1 lived, one piece per K-step (taps 0..7 of this slab)
-        const bool ppiece = slab >= 1 && slab + 1 < nslabs && tap < MAXP;
-
-        read_half(a1, b1, st, buf, sh, 1);
-        __builtin_amdgcn_sched_barrier(0);
+    auto w_addr = [&](int stoff, int kk) { return arow + stoff + ((((kk << 2) + fg) ^ (frow & 7)) << 4); };
+    auto x_addr = [&](int bufoff, int sh, int kk) { return brow + bufoff + sh * 128 + ((((kk << 2) + fg) ^ ((frow + sh) & 7)) << 4); };
+    auto pin_half = [&](u32x4 (&af)[NT], u32x4 (&bf)[MT]) {
 #pragma unroll
-        for (int t = 0; t < NTH; ++t) Mma<DT>::run(a0[t / MT], b0[t % MT], acc[t / MT][t % MT]);
-        __builtin_amdgcn_sched_barrier(0);
-        // this wave's reads of step s are back, its pieces of stage s + 1 (and any patch piece) have landed; after the
-        // barrier that holds for every wave, and ring slot st / the previous slab's patch are no longer read
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-        read_half(a0, b0, st ^ 1, nslab & 1, ndh * WP + ndw, 0);
-        // second half: MFMA(a1, b1) with the DMA pieces of stage s + 2 tucked in
-        constexpr int MPG = NTH / (RW + 1);
+        for (int i = 0; i < NT; ++i) pin_frag(af[i]);
 #pragma unroll
-        for (int g = 0; g < RW + 1; ++g) {
-            __builtin_amdgcn_sched_barrier(0);
-            if (g < RW) { if (refill) issue_w_piece(st, t2, s2, g); }
-            else if (ppiece) {
-#pragma unroll
-                for (int i = 0; i < MAXP; ++i) if (i == tap) issue_patch_piece((slab + 1) & 1, slab + 1, i);
+        for (int j = 0; j < MT; ++j) pin_frag(bf[j]);
+    };
+    constexpr int NTH = NT * MT, NR = NT + MT;
+    // MFMAs [T0, T1) of a group on fragments (af, bf).  The NR reads of the next fragment set ride on the head of the group (RLIM > 0):
+    // read r is issued behind MFMA r, so the last of them has the rest of the group - 17 MFMAs - to come back.
+    auto mma_group = [&](auto t0c, auto t1c, auto rlimc, const u32x4 (&af)[NT], const u32x4 (&bf)[MT], u32x4 (&naf)[NT], u32x4 (&nbf)[MT],
+                         unsigned wsb, unsigned xsb) {
+        constexpr int T0 = decltype(t0c)::value, T1 = decltype(t1c)::value, RLIM = decltype(rlimc)::value;
+        static_for<T1 - T0>([&](auto tt) {
+            constexpr int t = T0 + decltype(tt)::value;
+            MmaAsm<DT>::run(af[t / MT], bf[t % MT], acc[t / MT][t % MT]);
+            if constexpr (RLIM > 0) {
+                static_for<NR>([&](auto rc) {
+                    constexpr int r = decltype(rc)::value, tr = r;
+                    static_assert(NR <= RLIM, "every read in front of MFMA RLIM");
+                    if constexpr (tr == t) frag_read(naf, nbf, wsb, xsb, rc);
+                });
             }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int t = g * MPG; t < (g + 1) * MPG; ++t) Mma<DT>::run(a1[t / MT], b1[t % MT], acc[t / MT][t % MT]);
+        });
+    };
+
+    wait_vmcnt<0>();                                   // (the weight stages went first: they are in long before the patch)
+    __builtin_amdgcn_s_barrier();
+    const bool late = a.stagger && wave >= 4;
+    {
+        constexpr int H1 = 3 * NTH / 4;                                    // MFMAs of a LATE wave's first group in front of its barrier
+        constexpr int MPG = (NTH - NR) / (RW + 1) > 0 ? (NTH - NR) / (RW + 1) : 1;   // MFMAs between two DMA pieces
+        int stoff = 0;                                                     // ring slot of the current step (bytes): (s % NSLOT) * WSTAGE
+        int bufc = 0, bufn = pbytes;                                       // patch buffers of this slab / the next one
+        {
+            const unsigned wsb = w_addr(0, 0), xsb = x_addr(0, 0, 0);
+            static_for<NR>([&](auto r) { frag_read(a0, b0, wsb, xsb, r); });
         }
-#pragma unroll
-        for (int t = (RW + 1) * MPG; t < NTH; ++t) Mma<DT>::run(a1[t / MT], b1[t % MT], acc[t / MT][t % MT]);
-        __builtin_amdgcn_sched_barrier(0);
-        tap = ntap; slab = nslab; dh = ndh; dw = ndw;
+        for (int slab = 0; slab < nslabs; ++slab) {
+            const bool lastslab = slab + 1 == nslabs;
+            const int wsl_c = w_slab_offset(slab), wsl_n = w_slab_offset(lastslab ? slab : slab + 1);
+            // the next slab's patch goes into the other buffer (where slab - 1 lived), one piece per K-step.  (Piece 8 - patch rows
+            // 512.. - is issued behind the first fragment reads of the next slab: tap 0 reads rows < 512 only.)
+            bool in1;
+            const int ps1 = patch_slab_offset(lastslab ? slab : slab + 1, in1);
+            const bool pp = !lastslab;
+            static_for<9>([&](auto tapc) {
+                constexpr int tap = tapc, dh = tap / 3, dw = tap % 3, ntap = (tap + 1) % 9, ndh = ntap / 3, ndw = ntap % 3;
+                constexpr int t2 = (tap + NSLOT) % 9;                      // the tap of stage s + NSLOT, which refills this step's slot
+                // (the row shifts pass through an empty asm: hipcc otherwise hoists the fragment addresses of all nine bodies out of
+                //  the slab loop and spills to keep them)
+                int sh = dh * WP + dw, nsh = ndh * WP + ndw;
+                asm volatile("" : "+s"(sh), "+s"(nsh));
+                // first group: MFMA(a0, b0) [stage s, k-half 0] while the fragments of k-half 1 come in
+                const unsigned wsb1 = w_addr(stoff, 1), xsb1 = x_addr(bufc, sh, 1);
+                wait_lgkmcnt<0>();                     // a0 / b0 (read under the previous group) are back
+                pin_half(a0, b0);
+                // (the last K-step runs the same instruction stream with its barrier, look-ahead reads and DMA switched off: a
+                //  separate tail would meet this path in 112 accumulator phis)
+                const bool laststep = tap == 8 && lastslab;
+                // One instruction stream for both kinds of wave: a LATE wave takes the step's barrier behind MFMA H1, the others
+                // behind the whole group.  In front of it: this wave's reads of step s are back, its pieces of stage s + 1 (and any
+                // patch piece) have landed; behind it that holds for every wave, and ring slot `stoff` / the previous slab's patch
+                // are no longer read.
+                mma_group(IC<0>{}, IC<H1>{}, IC<H1>{}, a0, b0, a1, b1, wsb1, xsb1);
+                // What must have landed: stage s + 1.  Two slots: it is the only stage in flight (vmcnt 0).  Three slots: stage s + 2
+                // was issued behind it in the previous step - a patch piece first, then RW weight pieces - and stays in flight
+                // (vmcnt RW), unless that step was past the end of the refills (the last slab's taps 7 and 8 wait for everything).
+                auto wait_stage = [&]() {
+                    if (AF_DBG(1)) return;
+                    if (NSLOT == 2 || (tap >= 7 && lastslab)) wait_vmcnt<0>();
+                    else wait_vmcnt<RW>();
+                };
+                if (late && !laststep) {
+                    wait_lgkmcnt<0>();
+                    wait_stage();
+                    if (!AF_DBG(2)) __builtin_amdgcn_s_barrier();
+                }
+                mma_group(IC<H1>{}, IC<NTH>{}, IC<0>{}, a0, b0, a1, b1, 0u, 0u);
+                wait_lgkmcnt<0>();
+                if (!late && !laststep) {
+                    wait_stage();
+                    if (!AF_DBG(2)) __builtin_amdgcn_s_barrier();
+                }
+                pin_half(a1, b1);
+                // second group: MFMA(a1, b1) [stage s, k-half 1] while the fragments of stage s + 1, k-half 0 come in; then
+                // the DMA pieces of stage s + 2 (and one piece of the next slab's patch), MPG MFMAs apart
+                const int stnext = NSLOT == 2 ? (stoff ^ WSTAGE) : (stoff == (NSLOT - 1) * WSTAGE ? 0 : stoff + WSTAGE);
+                const unsigned wsb0 = w_addr(stnext, 0), xsb0 = x_addr(tap == 8 ? bufn : bufc, nsh, 0);
+                mma_group(IC<0>{}, IC<NR>{}, IC<NR>{}, a1, b1, a0, b0, wsb0, xsb0);   // (behind the last step: unused reads of valid LDS)
+                const bool refill = (tap + NSLOT < 9 || !lastslab) && !AF_DBG(4);
+                const int wsoff = (tap + NSLOT < 9 ? wsl_c : wsl_n) + t2 * tap_bytes;
+                static_for<RW + 1>([&](auto gc) {
+                    constexpr int g = gc;
+                    if (g == 0) { if (tap < MAXP && pp && !AF_DBG(16)) issue_patch_piece(bufn, ps1, in1, tap < MAXP ? tap : 0); }
+                    else if (refill) issue_w_piece(stoff, wsoff, g - 1);
+                    constexpr int T0 = NR + g * MPG < NTH ? NR + g * MPG : NTH;
+                    constexpr int T1 = g == RW ? NTH : (T0 + MPG < NTH ? T0 + MPG : NTH);
+                    mma_group(IC<T0>{}, IC<T1>{}, IC<0>{}, a1, b1, a0, b0, 0u, 0u);
+                });
+                stoff = stnext;
+            });
+            const int tb = bufc; bufc = bufn; bufn = tb;
+        }
     }
-    // last K-step
-    read_half(a1, b1, (S - 1) & 1, slab & 1, dh * WP + dw, 1);
-#pragma unroll
-    for (int t = 0; t < NTH; ++t) Mma<DT>::run(a0[t / MT], b0[t % MT], acc[t / MT][t % MT]);
-#pragma unroll
-    for (int t = 0; t < NTH; ++t) Mma<DT>::run(a1[t / MT], b1[t % MT], acc[t / MT][t % MT]);
+    AF_STAMP(1);
+    AF_STAMP(2);
+    mfma_drain();                                      // the accumulators are read by ordinary vector code from here on
 
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                      // every wave is done with the patches and the ring
+    // (the epilogue's lane-derived values start from an opaque copy of the lane id: nothing of its address arithmetic can be
+    //  computed - and kept in registers - across the K loop)
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    const int frow_e = lane_e & 15, fg_e = lane_e >> 4;
     f32x4 sc[NT], sf[NT];
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
-        sc[i] = *reinterpret_cast<const f32x4*>(a.scale + wn * 64 + i * 16 + fg * 4);
-        sf[i] = *reinterpret_cast<const f32x4*>(a.shift + wn * 64 + i * 16 + fg * 4);
+        sc[i] = *reinterpret_cast<const f32x4*>(a.scale + wn * 64 + i * 16 + fg_e * 4);
+        sf[i] = *reinterpret_cast<const f32x4*>(a.shift + wn * 64 + i * 16 + fg_e * 4);
     }
-    const int rr = lane >> 3, cc = (lane & 7) * 8;
+    const int rr = lane_e >> 3, cc = (lane_e & 7) * 8;
     if (!FUSEC) {
         // ---- epilogue: BN + ReLU + the one rounding, transposed through a per-wave patch (the patches / ring are dead),
         // whole 128-byte rows out.  Padded position p = r * WP + c -> output pixel (h0 + r, c - 1); halo columns dropped.
@@ -220,7 +317,7 @@ __global__ __launch_bounds__(512, 2) void conv133g_kernel(const C133GArgs a) {
             for (int i = 0; i < NT; ++i) {
                 f32x4 v = acc[i][j] * sc[i] + sf[i];
                 if (a.relu) { v[0] = relu_f(v[0]); v[1] = relu_f(v[1]); v[2] = relu_f(v[2]); v[3] = relu_f(v[3]); }
-                Vec4<DT>::store(reinterpret_cast<char*>(patch + frow * PROW + i * 16 + fg * 4), v);
+                Vec4<DT>::store(reinterpret_cast<char*>(patch + frow_e * PROW + i * 16 + fg_e * 4), v);
             }
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -234,6 +331,8 @@ __global__ __launch_bounds__(512, 2) void conv133g_kernel(const C133GArgs a) {
             }
             __builtin_amdgcn_wave_barrier();
         }
+        AF_STAMP(3); AF_STAMP(7);
+        AF_STAMP_FLUSH;
         return;
     }
 
@@ -245,13 +344,13 @@ __global__ __launch_bounds__(512, 2) void conv133g_kernel(const C133GArgs a) {
     char* T = reinterpret_cast<char*>(smem);
 #pragma unroll
     for (int j = 0; j < MT; ++j) {
-        const int p = (wm * MT + j) * 16 + frow;
+        const int p = (wm * MT + j) * 16 + frow_e;
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
             f32x4 v = acc[i][j] * sc[i] + sf[i];
             if (a.relu) { v[0] = relu_f(v[0]); v[1] = relu_f(v[1]); v[2] = relu_f(v[2]); v[3] = relu_f(v[3]); }
-            const int chunk = i * 2 + (fg >> 1);
-            Vec4<DT>::store(T + (wn * MPAD + p) * 128 + ((chunk ^ (p & 7)) << 4) + (fg & 1) * 8, v);
+            const int chunk = i * 2 + (fg_e >> 1);
+            Vec4<DT>::store(T + (wn * MPAD + p) * 128 + ((chunk ^ (p & 7)) << 4) + (fg_e & 1) * 8, v);
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -272,7 +371,7 @@ __global__ __launch_bounds__(512, 2) void conv133g_kernel(const C133GArgs a) {
         auto load_a = [&](uint4 (&dst)[NT], int h) {            // half-step h = (K-step h >> 1, k-half h & 1)
 #pragma unroll
             for (int i = 0; i < NT; ++i)
-                dst[i] = *reinterpret_cast<const uint4*>(a.w2 + ((long long)(ch0 + i * 16 + frow) * Cmid + h * 32 + fg * 8) * 2);
+                dst[i] = *reinterpret_cast<const uint4*>(a.w2 + ((long long)(ch0 + i * 16 + frow_e) * Cmid + h * 32 + fg_e * 8) * 2);
         };
         load_a(an[0], 0);
         load_a(an[1], 1);
@@ -280,7 +379,7 @@ __global__ __launch_bounds__(512, 2) void conv133g_kernel(const C133GArgs a) {
         for (int h = 0; h < 2 * WN; ++h) {
             if (h + 2 < 2 * WN) load_a(an[(h + 2) % 3], h + 2);
             uint4 bf[MT];
-            const char* xsb = T + ((h >> 1) * MPAD + wm * MT * 16 + frow) * 128 + (((((h & 1) << 2) + fg) ^ (frow & 7)) << 4);
+            const char* xsb = T + ((h >> 1) * MPAD + wm * MT * 16 + frow_e) * 128 + (((((h & 1) << 2) + fg_e) ^ (frow_e & 7)) << 4);
 #pragma unroll
             for (int j = 0; j < MT; ++j) bf[j] = *reinterpret_cast<const uint4*>(xsb + j * (16 * 128));
 #pragma unroll
@@ -290,14 +389,14 @@ __global__ __launch_bounds__(512, 2) void conv133g_kernel(const C133GArgs a) {
         f32x4 sc2[NT], sf2[NT];
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
-            sc2[i] = *reinterpret_cast<const f32x4*>(a.scale2 + ch0 + i * 16 + fg * 4);
-            sf2[i] = *reinterpret_cast<const f32x4*>(a.shift2 + ch0 + i * 16 + fg * 4);
+            sc2[i] = *reinterpret_cast<const f32x4*>(a.scale2 + ch0 + i * 16 + fg_e * 4);
+            sf2[i] = *reinterpret_cast<const f32x4*>(a.shift2 + ch0 + i * 16 + fg_e * 4);
         }
 #pragma unroll
         for (int j = 0; j < MT; ++j) {
 #pragma unroll
             for (int i = 0; i < NT; ++i)
-                *reinterpret_cast<f32x4*>(stg + frow * SROW + i * 16 + fg * 4) = acc[i][j] * sc2[i] + sf2[i];
+                *reinterpret_cast<f32x4*>(stg + frow_e * SROW + i * 16 + fg_e * 4) = acc[i][j] * sc2[i] + sf2[i];
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int it = 0; it < 2; ++it) {
@@ -327,18 +426,26 @@ __global__ __launch_bounds__(512, 2) void conv133g_kernel(const C133GArgs a) {
     }
 }
 
-template <int DT, int WN, int WM, bool FUSEC, int MT = 7>
-static int launch133g(const C133GArgs& a, hipStream_t stream) {
-    int lds = 2 * a.prows * 128 + 2 * WN * 64 * 128;
+template <int DT, int WN, int WM, bool FUSEC, int MT, int MAXP, int NSLOT>
+static int launch133g_n(const C133GArgs& a, hipStream_t stream) {
+    if (a.prows > 64 * MAXP) return set_error(AF_ERR_ARG, "conv133g: %d patch rows for %d pieces per wave", a.prows, MAXP);
+    int lds = 2 * a.prows * 128 + NSLOT * WN * 64 * 128;
     const int lds_c = WN * (WM * MT * 16) * 128 + 8 * 16 * (64 + 4) * 4;      // T + the per-wave fp32 staging rows
     if (FUSEC && lds_c > lds) lds = lds_c;
     const int lds_e = 8 * 16 * (64 + 8) * 2;                                   // the epilogue's per-wave patches
     if (lds < lds_e) lds = lds_e;
     if (lds > 160 * 1024) return set_error(AF_ERR_ARG, "conv133g: %d bytes of LDS needed", lds);
-    AF_SET_MAX_LDS((&conv133g_kernel<DT, WN, WM, MT, FUSEC>), 160 * 1024, "conv133g");
-    hipLaunchKernelGGL((conv133g_kernel<DT, WN, WM, MT, FUSEC>), dim3(a.frames * a.upf), dim3(512), lds, stream, a);
+    AF_SET_MAX_LDS((&conv133g_kernel<DT, WN, WM, MT, FUSEC, MAXP, NSLOT>), 160 * 1024, "conv133g");
+    hipLaunchKernelGGL((conv133g_kernel<DT, WN, WM, MT, FUSEC, MAXP, NSLOT>), dim3(a.frames * a.upf), dim3(512), lds, stream, a);
     AF_CHECK_LAUNCH("conv133g_kernel");
     return AF_OK;
+}
+
+// three ring slots (two K-steps of weights in flight) where the two patch buffers leave room for them (s4: 2 x 31 KB + 3 x 32 KB)
+template <int DT, int WN, int WM, bool FUSEC, int MT = 7, int MAXP = 9>
+static int launch133g(const C133GArgs& a, hipStream_t stream) {
+    if (!FUSEC && 2 * a.prows * 128 + 3 * WN * 64 * 128 <= 160 * 1024) return launch133g_n<DT, WN, WM, FUSEC, MT, MAXP, FUSEC ? 2 : 3>(a, stream);
+    return launch133g_n<DT, WN, WM, FUSEC, MT, MAXP, 2>(a, stream);
 }
 
 // rows of a frame one unit covers (0: the layer does not take this path)
@@ -380,6 +487,14 @@ static void fill133g(C133GArgs& a, const af_conv_desc* d, const void* in, const 
     a.kslabs = d->cin / 64; a.relu = d->relu;
     a.inv_wp = 1.0f / (float)a.WP;
     a.w2 = nullptr; a.scale2 = a.shift2 = nullptr; a.res = nullptr; a.Cout2 = 0; a.relu2 = 0;
+    const char* es = getenv("AF_G_STAGGER");
+    a.stagger = es ? atoi(es) : 1;
+#ifdef AF_STAMPS
+    const char* ep = getenv("AF_STAMP_PTR");
+    a.stamps = ep ? (unsigned long long*)strtoull(ep, nullptr, 0) : nullptr;
+    const char* ed = getenv("AF_G_DBG");
+    a.dbg = ed ? atoi(ed) : 0;
+#endif
 }
 
 // b (1x3x3) + c (1x1x1, + residual, + ReLU) of a bottleneck as one launch: true iff `db` takes the frame-resident path and
@@ -400,7 +515,7 @@ int conv133g_fused_run(const af_conv_desc* db, const void* in, const void* wb, c
     fill133g(a, db, in, wb, scale_b, shift_b);
     a.out = (char*)out; a.out_ld = out_ld ? out_ld : dc->cout;
     a.w2 = (const char*)wc; a.scale2 = scale_c; a.shift2 = shift_c; a.res = (const char*)residual; a.Cout2 = dc->cout; a.relu2 = dc->relu;
-    if (db->cout == 256) return db->dtype == AF_BF16 ? launch133g<AF_BF16, 4, 2, true>(a, stream) : launch133g<AF_F16, 4, 2, true>(a, stream);
+    if (db->cout == 256) return db->dtype == AF_BF16 ? launch133g<AF_BF16, 4, 2, true, 7, 5>(a, stream) : launch133g<AF_F16, 4, 2, true, 7, 5>(a, stream);
     return db->dtype == AF_BF16 ? launch133g<AF_BF16, 2, 4, true>(a, stream) : launch133g<AF_F16, 2, 4, true>(a, stream);
 }
 
@@ -409,8 +524,10 @@ int conv133g_run(const af_conv_desc* d, const void* in, const void* w_packed, co
     C133GArgs a;
     fill133g(a, d, in, w_packed, scale, shift);
     a.out = (char*)out; a.out_ld = out_ld ? out_ld : d->cout;
-    if (d->cout == 256) return d->dtype == AF_BF16 ? launch133g<AF_BF16, 4, 2, false>(a, stream) : launch133g<AF_F16, 4, 2, false>(a, stream);
+    if (d->cout == 256) return d->dtype == AF_BF16 ? launch133g<AF_BF16, 4, 2, false, 7, 5>(a, stream) : launch133g<AF_F16, 4, 2, false, 7, 5>(a, stream);
     if (d->cout == 64) return d->dtype == AF_BF16 ? launch133g<AF_BF16, 1, 8, false, 4>(a, stream) : launch133g<AF_F16, 1, 8, false, 4>(a, stream);
+    // pieces per wave: 256 channels: <= 224 + 2 WP + 1 <= 296 patch rows (5); 128 channels: the s3 band of 472 rows takes 8
+    if (a.prows <= 512) return d->dtype == AF_BF16 ? launch133g<AF_BF16, 2, 4, false, 7, 8>(a, stream) : launch133g<AF_F16, 2, 4, false, 7, 8>(a, stream);
     return d->dtype == AF_BF16 ? launch133g<AF_BF16, 2, 4, false>(a, stream) : launch133g<AF_F16, 2, 4, false>(a, stream);
 }
 
