@@ -106,6 +106,21 @@ template <> struct MmaAsm<AF_F16> {
     }
 };
 __device__ __forceinline__ void mfma_drain() { asm volatile("s_nop 15\n\ts_nop 7" ::: "memory"); }   // > the 8-pass MFMA's 12 wait states
+// What rides behind MFMA t of a K-step's second MFMA group: NP DMA pieces and NR fragment reads dealt out one per MFMA in the
+// pattern piece, read, read, piece, ... (a piece first: the DMA of the stage two ahead wants all the lead it can get; the reads
+// only have to be back by the next group) until one kind runs out.  group2_slot(t): >= 0: piece index; < 0: read index -1 - r;
+// kNoSlot: nothing.
+constexpr int kNoSlot = 1 << 20;
+constexpr int group2_slot(int t, int NP, int NR) {
+    int p = 0, r = 0;
+    for (int i = 0;; ++i) {
+        int what = kNoSlot;
+        if (p < NP && (i % 3 == 0 || r >= NR)) what = p++;
+        else if (r < NR) what = -1 - r++;
+        if (i == t) return what;
+        if (what == kNoSlot) return kNoSlot;
+    }
+}
 // compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{}) (asm immediates need constants)
 template <int I> struct IC { static constexpr int value = I; constexpr operator int() const { return I; } };
 template <int N, int I = 0, class F> __device__ __forceinline__ void static_for(F&& f) {

@@ -26,6 +26,20 @@
 
 namespace af {
 
+// Diagnostic build (-DAF_STAMPS, tools/stamps_lib.sh; never the shipped library): shader-clock stamps around the phases of a tile
+#ifdef AF_STAMPS
+#define AF_STAMP_DECL unsigned long long stamp_v[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define AF_DBG(bit) (a.dbg & (bit))
+#define AF_STAMP(slot) stamp_v[slot] = (slot) >= 6 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime()
+#define AF_STAMP_FLUSH do { if (a.stamps && lane < 8) a.stamps[((long long)blockIdx.x * 8 + wave) * 8 + lane] = \
+    lane == 0 ? stamp_v[0] : lane == 1 ? stamp_v[1] : lane == 2 ? stamp_v[2] : lane == 3 ? stamp_v[3] : lane == 4 ? stamp_v[4] : lane == 5 ? stamp_v[5] : lane == 6 ? stamp_v[6] : stamp_v[7]; } while (0)
+#else
+#define AF_STAMP_DECL do {} while (0)
+#define AF_DBG(bit) false
+#define AF_STAMP(slot) do {} while (0)
+#define AF_STAMP_FLUSH do {} while (0)
+#endif
+
 struct ConvArgs {
     const char* in;
     const char* w;
@@ -54,6 +68,10 @@ struct ConvArgs {
     int ksplit;
     float* ws;
     long long ws_bytes;  // caller's workspace (ws == nullptr or too small: no split)
+#ifdef AF_STAMPS
+    unsigned long long* stamps;   // diagnostic build only (tools/stamps_lib.sh): [workgroup][wave][8] shader-clock / wall-clock stamps
+    int dbg;                      // timing-only ablations of the MFMA-bound K loops (AF_G_DBG): 1 no vmcnt wait, 2 no barrier, 4 no DMA
+#endif
 };
 
 // NW = WN*WM*KS = 8 waves (512 threads); wave (wn, wm) owns a (BN/WN) x (BM/WM) sub-tile of 16x16
@@ -205,14 +223,17 @@ __global__ __launch_bounds__(WN * WM * KS * 64, MINW) void conv_igemm_kernel(con
     const int s_lo = SPLITK ? (int)((long long)blockIdx.y * S_all / a.ksplit) : 0;
     const int S = (SPLITK ? (int)((long long)(blockIdx.y + 1) * S_all / a.ksplit) : S_all) - s_lo;
     if (SPLITK) for (int i = 0; i < s_lo; ++i) advance();
+    AF_STAMP_DECL;
+    AF_STAMP(0); AF_STAMP(6);
     issue_stage(0);
     if (S > 1 && !(LEAN && a.ring == 2)) issue_stage(1);
 
+    AF_STAMP(1);
     const int frow = lane & 15, fg = lane >> 4;
     constexpr int NKK = 2 / KS;                                   // k-halves of a stage this wave multiplies
     const int kk0 = KS == 2 ? kgroup : 0;
     const int wrow = (wn * WTN + frow) * 8, xrow = BN * 8 + (wm * WTM + frow) * 8;
-    if (LEAN || NKK == 1 || TM < 4) {
+    if constexpr (LEAN || NKK == 1 || TM < 4) {
         // HBM-bound short-K variants (and the K-split layout): smallest register footprint, one barrier per
         // K-step, all DMA pieces of stage s+2 issued right after it.
         auto multiply = [&](int st_) {
@@ -253,8 +274,118 @@ __global__ __launch_bounds__(WN * WM * KS * 64, MINW) void conv_igemm_kernel(con
                 st = (st == 2) ? 0 : st + 1;
             }
         }
+    } else if constexpr (DT != AF_F32 && !DUAL && !(LEAN || NKK == 1 || TM < 4)) {
+        // ---- MFMA-bound variants, 16-bit operands, one input (round 4; the projection blocks' second K segment doubles the
+        // descriptors and offsets the DMA issue selects from - 106 scalar registers and spills next to the DMA - and keeps the builtin loop): the K loop as asm statements, issued in program order - MFMAs
+        // accumulating in place, LDS fragment reads hipcc does not count, LDS-DMA, the kernel's own waits (af_common.h) - on the
+        // structure conv133g measured its way to (in-kernel stamps): software-pipelined by k-halves; the NR = TN + TM
+        // fragment reads of the NEXT half ride on the first NR MFMAs of a group, one ds_read_b128 per MFMA, so no read burst stands
+        // between a barrier and the matrix pipe; the DMA pieces of stage s + NSTAGE follow, spread over the rest of the second
+        // group; waves 4-7 (the SIMD partners of 0-3) take the step's one barrier H1 MFMAs into their first group instead of behind
+        // it.  One instruction stream for both kinds of wave and for the last step (separate paths would meet in TN * TM
+        // accumulator phis).  What hipcc had made of the builtin form of this loop ran at 0.79 of the MFMA rate with every
+        // memory operation and barrier switched off (AF_G_DBG = 7 of the stamp build), 0.67 with them.
+        constexpr int NTH = TN * TM, NR = TN + TM;
+        constexpr int H1 = 3 * NTH / 4;
+        static_assert(NR <= H1 && NR + PER_WAVE <= NTH, "reads in front of a LATE wave's barrier; a DMA piece or a read per MFMA");
+        u32x4 a0[TN], b0[TM], a1[TN], b1[TM];
+        const unsigned wb[2] = {lds0 + (unsigned)((wn * WTN + frow) * 128 + (((0 + fg) ^ (frow & 7)) << 4)),
+                                lds0 + (unsigned)((wn * WTN + frow) * 128 + (((4 + fg) ^ (frow & 7)) << 4))};
+        const unsigned xb[2] = {lds0 + (unsigned)((BN + wm * WTM + frow) * 128 + (((0 + fg) ^ (frow & 7)) << 4)),
+                                lds0 + (unsigned)((BN + wm * WTM + frow) * 128 + (((4 + fg) ^ (frow & 7)) << 4))};
+        auto frag_read = [&](u32x4 (&af)[TN], u32x4 (&bf)[TM], unsigned wsb, unsigned xsb, auto idx) {
+            constexpr int r = decltype(idx)::value;
+            if constexpr (r < TN) af[r] = lds_read16_uncounted<r * (16 * 128)>(wsb);
+            else if constexpr (r < NR) bf[r - TN] = lds_read16_uncounted<(r - TN) * (16 * 128)>(xsb);
+        };
+        auto pin_half = [&](u32x4 (&af)[TN], u32x4 (&bf)[TM]) {
+#pragma unroll
+            for (int i = 0; i < TN; ++i) pin_frag(af[i]);
+#pragma unroll
+            for (int j = 0; j < TM; ++j) pin_frag(bf[j]);
+        };
+        // MFMAs [T0, T1) of a group on (af, bf); with READS, read r of the next fragment set is issued behind MFMA r
+        auto mma_group = [&](auto t0c, auto t1c, auto readsc, const u32x4 (&af)[TN], const u32x4 (&bf)[TM], u32x4 (&naf)[TN], u32x4 (&nbf)[TM],
+                             unsigned wsb, unsigned xsb) {
+            constexpr int T0 = decltype(t0c)::value, T1 = decltype(t1c)::value;
+            static_for<T1 - T0>([&](auto tt) {
+                constexpr int t = T0 + decltype(tt)::value;
+                MmaAsm<DT>::run(af[t / TM], bf[t % TM], acc[t / TM][t % TM]);
+                if constexpr (decltype(readsc)::value && t < NR) frag_read(naf, nbf, wsb, xsb, IC<t>{});
+            });
+        };
+        // prologue: (the generic prologue above issued stages 0 and 1) stage 2 of a three-slot ring, then stage 0 landed - vmcnt counts
+        // in issue order: all but the younger stages
+        if (NSTAGE == 3 && S > 2) issue_stage(2);
+        if (S >= NSTAGE) wait_vmcnt<(NSTAGE - 1) * PER_WAVE>(); else if (S == 2) wait_vmcnt<PER_WAVE>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        static_for<NR>([&](auto r) { frag_read(a0, b0, wb[0], xb[0], r); });
+        const bool late = wave >= 4;
+        int stoff = 0;                                             // ring slot of stage s (bytes)
+        for (int s = 0; s < S; ++s) {
+            const bool laststep = s + 1 == S;
+            const int stnext = stoff == (NSTAGE - 1) * STAGE_BYTES ? 0 : stoff + STAGE_BYTES;
+            // first group: MFMA(a0, b0) [stage s, k-half 0] while the fragments of k-half 1 come in
+            wait_lgkmcnt<0>();
+            pin_half(a0, b0);
+            // what must have landed in front of the barrier: stage s + 1.  Two slots: the only stage in flight.  Three slots: the
+            // pieces of stage s + 2 (or their empty stand-ins) were issued behind it in the previous step and stay in flight; at
+            // K-step 0 the younger operations are the prologue's (stage 2 if the layer has one).
+            auto wait_stage = [&]() {
+                if (AF_DBG(1)) return;
+                if (NSTAGE == 2 || (s == 0 && S <= 2)) wait_vmcnt<0>(); else wait_vmcnt<PER_WAVE>();
+            };
+            mma_group(IC<0>{}, IC<H1>{}, IC<1>{}, a0, b0, a1, b1, wb[1] + stoff, xb[1] + stoff);
+            if (late && !laststep) {
+                wait_lgkmcnt<0>();
+                wait_stage();
+                if (!AF_DBG(2)) __builtin_amdgcn_s_barrier();
+            }
+            mma_group(IC<H1>{}, IC<NTH>{}, IC<0>{}, a0, b0, a1, b1, 0u, 0u);
+            wait_lgkmcnt<0>();
+            if (!late && !laststep) {
+                wait_stage();
+                if (!AF_DBG(2)) __builtin_amdgcn_s_barrier();
+            }
+            pin_half(a1, b1);
+            // second group: MFMA(a1, b1) [stage s, k-half 1]; behind its MFMAs, one each, the DMA pieces of stage s + NSTAGE into the slot
+            // this step has just left and the fragment reads of stage s + 1, k-half 0 (group2_slot: piece, read, read, piece, ...;
+            // behind the last step: unused reads of valid LDS).
+            // (The stage's scalar offsets are computed once, not per piece; past the last refill the pieces are still issued, through
+            //  an empty descriptor - every lane out of range: zeros into a slot nobody reads again - so the step has no branch per
+            //  piece and every step puts PER_WAVE operations on the vmcnt queue.)
+            const bool refill = s + NSTAGE < S && !AF_DBG(4);
+            const int wsoff = __builtin_amdgcn_readfirstlane(tap * a.CinP * ES + kc * 128);
+            const int xsoff = __builtin_amdgcn_readfirstlane(((dt * a.H + dh) * a.W + dw) * a.Cin * ES + kc * 128);
+            i32x4 wd = wdesc, xd = xdesc;
+            if (!refill) { wd[2] = 0; xd[2] = 0; }
+            const bool lastk = kc + 1 < a.kpt || clast;            // this lane's chunk of the slab is real
+            const unsigned tapbit = (unsigned)tap;
+            // (the last step has no barrier between one wave's DMA issue and another wave's reads of this step's slot: its empty
+            //  pieces go to the NEXT slot, which nobody reads or refills any more)
+            const unsigned dst0 = lds0 + (laststep ? stnext : stoff) + wave * (8 * 128);
+            const unsigned wsb0 = wb[0] + stnext, xsb0 = xb[0] + stnext;
+            static_for<NTH>([&](auto tc) {
+                constexpr int t = tc, slot = group2_slot(t, PER_WAVE, NR);
+                MmaAsm<DT>::run(a1[t / TM], b1[t % TM], acc[t / TM][t % TM]);
+                if constexpr (slot != kNoSlot && slot < 0) frag_read(a0, b0, wsb0, xsb0, IC<-1 - slot>{});
+                else if constexpr (slot != kNoSlot) {
+                    constexpr int g = slot;
+                    if constexpr (g < RW) blds16_m0(woff[g], wd, wsoff, __builtin_amdgcn_readfirstlane(dst0 + g * (GR * 128)));
+                    else {
+                        const bool ok = ((xmask[g - RW] >> tapbit) & 1u) && lastk;
+                        blds16_m0(ok ? xoff[g - RW] : kOutOfRange, xd, xsoff, __builtin_amdgcn_readfirstlane(dst0 + g * (GR * 128)));
+                    }
+                }
+            });
+            if (refill) advance();
+            stoff = stnext;
+        }
+        wait_vmcnt<0>();                                           // (the empty stand-in pieces of the last steps write zeros into the ring: the epilogue reuses it)
+        wait_lgkmcnt<0>();                                         // (the last step's look-ahead reads land in registers the epilogue reuses)
+        mfma_drain();                                              // the accumulators are read by ordinary vector code from here on
     } else {
-        // MFMA-bound variants: software-pipelined by k-HALVES.  The fragments of a half are read from LDS while
+        // MFMA-bound variants, fp32 (four exact-fp32 MFMAs per chunk) and the two-input projection blocks: software-pipelined by k-HALVES.  The fragments of a half are read from LDS while
         // the MFMAs of the previous half run, so the matrix pipe never waits for the LDS fill that follows a
         // barrier; the barrier (+ the counted vmcnt that makes stage s+1 visible) sits between the two MFMA
         // groups of a stage, and the LDS-DMA pieces of the look-ahead stage are tucked between the MFMAs of the
@@ -294,14 +425,14 @@ __global__ __launch_bounds__(WN * WM * KS * 64, MINW) void conv_igemm_kernel(con
                 // this wave's reads of stage s are back and its pieces of stage s+1 (the only one in flight) have
                 // landed; after the barrier that holds for every wave
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                wait_vmcnt<0>();
-                __builtin_amdgcn_s_barrier();
+                if (!AF_DBG(1)) wait_vmcnt<0>();
+                if (!AF_DBG(2)) __builtin_amdgcn_s_barrier();
                 read_half(a0, b0, st1, 0);
                 // ---- second half: MFMA(a1,b1) with the DMA pieces of stage s+2 in the gaps; sched_barrier pins the interleave
 #pragma unroll
                 for (int g = 0; g < PER_WAVE; ++g) {
                     __builtin_amdgcn_sched_barrier(0);
-                    if (refill) issue_piece(st, g);
+                    if (refill && !AF_DBG(4)) issue_piece(st, g);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int t = g * MPG; t < (g + 1) * MPG && t < NTH; ++t) MMA::run(a1[t / TM], b1[t % TM], acc[t / TM][t % TM]);
@@ -328,7 +459,7 @@ __global__ __launch_bounds__(WN * WM * KS * 64, MINW) void conv_igemm_kernel(con
 #pragma unroll
                 for (int g = 0; g < PER_WAVE; ++g) {
                     __builtin_amdgcn_sched_barrier(0);
-                    if (refill) issue_piece(nst, g);
+                    if (refill && !AF_DBG(4)) issue_piece(nst, g);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int t = g * MPG; t < (g + 1) * MPG && t < NTH; ++t) MMA::run(a0[t / TM], b0[t % TM], acc[t / TM][t % TM]);
@@ -340,8 +471,8 @@ __global__ __launch_bounds__(WN * WM * KS * 64, MINW) void conv_igemm_kernel(con
                 // this wave's reads of stage s are back (they were issued a whole MFMA group ago) and its pieces of
                 // stage s+1 have landed; after the barrier that holds for every wave
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (refill) wait_vmcnt<PER_WAVE>(); else wait_vmcnt<0>();
-                __builtin_amdgcn_s_barrier();
+                if (!AF_DBG(1)) { if (refill) wait_vmcnt<PER_WAVE>(); else wait_vmcnt<0>(); }
+                if (!AF_DBG(2)) __builtin_amdgcn_s_barrier();
                 read_half(a0, b0, st1, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 // ---- second half: MFMA(a1,b1) runs under the LDS reads just issued
@@ -363,6 +494,7 @@ __global__ __launch_bounds__(WN * WM * KS * 64, MINW) void conv_igemm_kernel(con
     // transposes its sub-tile through a private fp32 LDS patch ([position][WTN + 4 pad] floats; the ring is
     // dead by now) and then streams whole rows: 16 bytes per lane, full 128-byte lines per row for the
     // output store AND the residual load.  Residual add and ReLU happen in fp32 before the one rounding.
+    AF_STAMP(2);
     __builtin_amdgcn_s_barrier();                      // every wave has finished reading the ring
     int patch_off = 0;                                 // floats
     if (KS == 2) {
@@ -508,6 +640,8 @@ __global__ __launch_bounds__(WN * WM * KS * 64, MINW) void conv_igemm_kernel(con
         }
         __builtin_amdgcn_wave_barrier();
     }
+    AF_STAMP(3); AF_STAMP(7);
+    AF_STAMP_FLUSH;
 }
 
 template <int DT, int BN, int BM, int WN, int WM, int KS, int MINW, bool DUAL, int NSTAGE = 3, bool SPLITK = false, int BMR = BM>
@@ -744,6 +878,10 @@ static int conv_common(const af_conv_desc* d, const void* in, const void* w_pack
     a.relu = d->relu; a.out_ld = out_ld;
     AF_REQUIRE(aligned16(workspace) && workspace_bytes >= 0, "conv: the workspace must be 16-byte aligned");
     a.ws = (float*)workspace; a.ws_bytes = workspace ? workspace_bytes : 0;
+#ifdef AF_STAMPS
+    { const char* ep = getenv("AF_STAMP_PTR"); a.stamps = ep ? (unsigned long long*)strtoull(ep, nullptr, 0) : nullptr;
+      const char* ed = getenv("AF_G_DBG"); a.dbg = ed ? atoi(ed) : 0; }
+#endif
     AF_REQUIRE(d->tpool >= 0 && d->tpool <= 2, "conv: tpool must be 0, 1 (temporal pairs) or 2 (2x2 pixels)");
     a.tpool = d->tpool;
     AF_REQUIRE(a.tpool != 1 || (to % 2 == 0), "conv: fused temporal pool needs an even number of output frames (%d)", to);

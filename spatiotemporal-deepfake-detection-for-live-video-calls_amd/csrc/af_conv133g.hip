@@ -214,7 +214,7 @@ __global__ __launch_bounds__(512, 2) void conv133g_kernel(const C133GArgs a) {
     const bool late = a.stagger && wave >= 4;
     {
         constexpr int H1 = 3 * NTH / 4;                                    // MFMAs of a LATE wave's first group in front of its barrier
-        constexpr int MPG = (NTH - NR) / (RW + 1) > 0 ? (NTH - NR) / (RW + 1) : 1;   // MFMAs between two DMA pieces
+        static_assert(NR + RW + 1 <= NTH, "a DMA piece or a read per MFMA of the second group");
         int stoff = 0;                                                     // ring slot of the current step (bytes): (s % NSLOT) * WSTAGE
         int bufc = 0, bufn = pbytes;                                       // patch buffers of this slab / the next one
         {
@@ -272,16 +272,16 @@ __global__ __launch_bounds__(512, 2) void conv133g_kernel(const C133GArgs a) {
                 // the DMA pieces of stage s + 2 (and one piece of the next slab's patch), MPG MFMAs apart
                 const int stnext = NSLOT == 2 ? (stoff ^ WSTAGE) : (stoff == (NSLOT - 1) * WSTAGE ? 0 : stoff + WSTAGE);
                 const unsigned wsb0 = w_addr(stnext, 0), xsb0 = x_addr(tap == 8 ? bufn : bufc, nsh, 0);
-                mma_group(IC<0>{}, IC<NR>{}, IC<NR>{}, a1, b1, a0, b0, wsb0, xsb0);   // (behind the last step: unused reads of valid LDS)
                 const bool refill = (tap + NSLOT < 9 || !lastslab) && !AF_DBG(4);
                 const int wsoff = (tap + NSLOT < 9 ? wsl_c : wsl_n) + t2 * tap_bytes;
-                static_for<RW + 1>([&](auto gc) {
-                    constexpr int g = gc;
-                    if (g == 0) { if (tap < MAXP && pp && !AF_DBG(16)) issue_patch_piece(bufn, ps1, in1, tap < MAXP ? tap : 0); }
-                    else if (refill) issue_w_piece(stoff, wsoff, g - 1);
-                    constexpr int T0 = NR + g * MPG < NTH ? NR + g * MPG : NTH;
-                    constexpr int T1 = g == RW ? NTH : (T0 + MPG < NTH ? T0 + MPG : NTH);
-                    mma_group(IC<T0>{}, IC<T1>{}, IC<0>{}, a1, b1, a0, b0, 0u, 0u);
+                // behind the MFMAs of the group, one each (group2_slot: piece, read, read, piece, ...): the patch piece, the RW weight
+                // pieces, the NR look-ahead reads (behind the last step: unused reads of valid LDS)
+                static_for<NTH>([&](auto tc) {
+                    constexpr int t = tc, slot = group2_slot(t, RW + 1, NR);
+                    MmaAsm<DT>::run(a1[t / MT], b1[t % MT], acc[t / MT][t % MT]);
+                    if constexpr (slot != kNoSlot && slot < 0) frag_read(a0, b0, wsb0, xsb0, IC<-1 - slot>{});
+                    else if constexpr (slot == 0) { if (tap < MAXP && pp && !AF_DBG(16)) issue_patch_piece(bufn, ps1, in1, tap < MAXP ? tap : 0); }
+                    else if constexpr (slot != kNoSlot) { if (refill) issue_w_piece(stoff, wsoff, slot - 1); }
                 });
                 stoff = stnext;
             });
