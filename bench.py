@@ -242,6 +242,8 @@ def roofline_report(eng, args, line, reps=5):
         line["roofline"]["traffic_uncorrected"] = round(raw)
         line["roofline"]["traffic_unit"] = ("HBM bytes per launch = 2*FETCH_SIZE + WRITE_SIZE (gfx950 correction; "
                                             "traffic_uncorrected = FETCH_SIZE + WRITE_SIZE as counted), " + src)
+        line["roofline"]["traffic_source"] = ("committed profile (%s: separate rocprofv3 --pmc passes of this same command), NOT measured "
+                                              "in this run - PMC counters cannot be read from inside the timed process" % src)
     # the fraction of the Conv3d MFMA roofline, per conv class and for the whole model (all launches, pack and head included)
     mf = {}
     for cls, v in per_class.items():
@@ -374,9 +376,11 @@ def bench_dualrun_rgb(args, rank, world, dev):
         # share of the AltFreezing forward in a step (events on the launch stream)
         e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
         net.rgb_from_features = True
-        e[0].record(); rgb2 = clf.network.forward_clips_u8(ud, return_pooled=True); e[1].record()
-        net(Ad, Ld, rgb2["pooled"].view(B, 1, -1), key_padding_mask=mask); e[2].record()
-        net.rgb_from_features = False
+        try:
+            e[0].record(); rgb2 = clf.network.forward_clips_u8(ud, return_pooled=True); e[1].record()
+            net(Ad, Ld, rgb2["pooled"].view(B, 1, -1), key_padding_mask=mask); e[2].record()
+        finally:
+            net.rgb_from_features = False
         torch.cuda.synchronize(dev)
         ms["altfreezing"], ms["dual_rgb"] = e[0].elapsed_time(e[1]), e[1].elapsed_time(e[2])
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -624,11 +628,10 @@ def bench_aligner(args, rank, world, dev):
         dist.destroy_process_group()
 
 
-def bench_conv3x3x3(args, rank, world, dev):
-    """The literal "MFMA % on 3x3x3 Conv3d" of BASELINE.json's metric.  SYNTHETIC - NOT A LAYER OF THE REFERENCE MODEL (its
-    bottleneck is factorised into 3x1x1 + 1x3x3, SURVEY fact 3): the generic kT x kH x kW implicit-GEMM kernel with a full
-    3x3x3 kernel (round 3: the frame-resident halo kernel conv133g with kT = 3) on the geometry of SURVEY 8d shape #4 (64 -> 64 @ 32x56x56, K = 1728) and #18 (256 -> 256 @ 16x14x14,
-    K = 6912), batch 16, Conv3d + BN + ReLU in one launch; parity against F.conv3d (fp32, CPU) on clip 0."""
+def conv3x3x3_shapes(args, rank, dev, steps=None):
+    """[per-shape record] of the synthetic 3x3x3 Conv3d + BN + ReLU launches (see bench_conv3x3x3), device time from events on
+    the launch stream; also called from the default --model i3d line (`conv3x3x3` sub-record)."""
+    steps = steps or args.steps
     import ctypes as C
     import torch.nn.functional as F
     from af_mi355x import _lib
@@ -665,11 +668,11 @@ def bench_conv3x3x3(args, rank, world, dev):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize(dev)
         e0.record()
-        for _ in range(args.steps):
+        for _ in range(steps):
             launch()
         e1.record()
         torch.cuda.synchronize(dev)
-        ms = e0.elapsed_time(e1) / args.steps
+        ms = e0.elapsed_time(e1) / steps
         macs = B * t * hw * hw * cout * cin * 27
         # parity: clip 0 against F.conv3d in fp32 on the SAME rounded operands (weights rounded to the compute dtype as the
         # packer does), so the difference is accumulation order + the output rounding only
@@ -683,6 +686,17 @@ def bench_conv3x3x3(args, rank, world, dev):
                        "us_per_launch": round(1e3 * ms, 2), "gflop_per_launch": round(2 * macs / 1e9, 2),
                        "achieved": round(tf, 1), "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
                        "frac": round(tf / PEAK_TFLOPS[args.dtype], 4), "max_rel_err_vs_F_conv3d_fp32": rel})
+        del x, xd, out
+    return shapes
+
+
+def bench_conv3x3x3(args, rank, world, dev):
+    """The literal "MFMA % on 3x3x3 Conv3d" of BASELINE.json's metric.  SYNTHETIC - NOT A LAYER OF THE REFERENCE MODEL (its
+    bottleneck is factorised into 3x1x1 + 1x3x3, SURVEY fact 3): the generic kT x kH x kW implicit-GEMM kernel with a full
+    3x3x3 kernel (round 3: the frame-resident halo kernel conv133g with kT = 3) on the geometry of SURVEY 8d shape #4 (64 -> 64 @ 32x56x56, K = 1728) and #18 (256 -> 256 @ 16x14x14,
+    K = 6912), batch 16, Conv3d + BN + ReLU in one launch; parity against F.conv3d (fp32, CPU) on clip 0."""
+    B = args.batch
+    shapes = conv3x3x3_shapes(args, rank, dev)
     tot_flop = sum(s["gflop_per_launch"] for s in shapes)
     tot_ms = sum(s["us_per_launch"] for s in shapes) / 1e3
     line = {"metric": "MFMA % on 3x3x3 Conv3d (synthetic: not a layer of the reference model)",
@@ -777,7 +791,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16, help="clips per GPU")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
-    ap.add_argument("--cpu-clips", type=int, default=4, help="clips in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-clips", type=int, default=4, help="clips in the CPU baseline sample (0 = skip; 16 = the B=16 figure of SURVEY 8d, ~1 min of CPU time: the default 4 keeps the driver's run short)")
     ap.add_argument("--model", default="i3d", choices=["i3d", "slowfast", "ftcn_tt", "dualrun", "dualrun_rgb", "aligner", "conv3x3x3", "stream"],
                     help="i3d = the i3d_ori plugin (BASELINE metric); slowfast = the two-pathway SlowFast-R50, ftcn_tt = the "
                          "reference's second plugin (next rows of SURVEY 8f)")
@@ -903,6 +917,32 @@ def main():
         line["model_tflops_per_s"] = round(2 * total_macs / B * clips_per_s / 1e12, 2)
         if not args.no_roofline:
             roofline_report(eng, args, line)
+        if args.model == "i3d" and not args.no_roofline and args.dtype != "f32":
+            # BASELINE.json's literal second metric, timed by whoever runs this line: SYNTHETIC (the reference model has no 3x3x3
+            # conv: its bottleneck is 3x1x1 + 1x3x3) - the frame-resident halo kernel with kT = 3 on SURVEY 8d shapes #4 / #18
+            shp = conv3x3x3_shapes(args, rank, dev, steps=max(args.steps, 10))
+            line["conv3x3x3"] = {"metric": "MFMA % on 3x3x3 Conv3d", "synthetic": True,
+                                 "note": "not a layer of the reference model (SURVEY fact 3); Conv3d 3x3x3 + BN + ReLU, batch %d, "
+                                         "one launch per shape, events on the launch stream" % B,
+                                 "shapes": shp}
+            # the reference callers' batch sizes (test/af_realtime.py:318-360 runs 1-3 windows per call, new_demo_test/run_meta.json
+            # 8): forward latency of the same engine family, device-resident fp32 input, wall clock over back-to-back steps
+            lat = {}
+            with torch.inference_mode():
+                for b in (1, 2, 4, 8):
+                    if b >= B:
+                        continue
+                    xb = x[:b]
+                    for _ in range(3):
+                        clf(xb)
+                    torch.cuda.synchronize(dev)
+                    t0 = time.perf_counter()
+                    nrep = 30
+                    for _ in range(nrep):
+                        clf(xb)
+                    torch.cuda.synchronize(dev)
+                    lat[str(b)] = round(1e3 * (time.perf_counter() - t0) / nrep, 4)
+            line["latency_ms_by_batch"] = lat
         if args.cpu_clips > 0:
             n = min(args.cpu_clips, B)
             try:

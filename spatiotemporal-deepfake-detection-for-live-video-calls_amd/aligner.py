@@ -243,13 +243,14 @@ class FasterCropAlignXRay:
         # one C call per copy thread (af_stage_rows_u8: a memcpy per row; ctypes releases the GIL): numpy copies a column-cut view
         # with ~100 ns of iterator overhead per row - 8 000 rows per clip, half of the whole call
         rects = (_lib.StageRect * len(images))()
+        keep = []              # every array whose address goes into `rects` - contiguous temporaries included - lives until the copies return
         for i, (im, o) in enumerate(zip(images, offs)):
             if im.ndim == 3:
                 im = im.reshape(im.shape[0], im.shape[1] * 3) if im.flags.c_contiguous else np.ascontiguousarray(im).reshape(im.shape[0], -1)
             if im.strides[1] != 1:
                 im = np.ascontiguousarray(im)
+            keep.append(im)
             rects[i] = _lib.StageRect(im.ctypes.data, o, im.strides[0] if im.shape[0] > 1 else im.shape[1], im.shape[0], im.shape[1])
-        keep = images                                               # (the arrays stay alive until the copies below have returned)
         base = host.data_ptr()
         # (staging in four chunks, each crossing PCIe while the next is copied, was tried: the extra pool round trips and small
         #  copies cost more than the overlap gained - host-inclusive 1 780 -> 860 clips/s)
@@ -323,6 +324,10 @@ class StreamingCropAligner:
         self._hv = self.host.numpy()
         self.frames = []                   # (info, crop shape, slot) of the frames still resident, oldest first
         self.count = 0
+        # slot reuse is ordered by events, not by assumptions about the caller's streams / pacing: the H2D copy out of a pinned
+        # slot (recorded per slot), and the last warp launch that may still read the device twins (one event for all slots)
+        self._h2d_done = [None] * self.capacity
+        self._warp_done = None
 
     def push(self, info, crop: np.ndarray) -> None:
         """a captured frame of the track: landmark record ``(_, ldm5, ldm68, box)`` + its HxWx3 uint8 crop"""
@@ -333,11 +338,17 @@ class StreamingCropAligner:
         slot = self.count % self.capacity
         self.count += 1
         lo = slot * self.slot_bytes
+        if self._h2d_done[slot] is not None:
+            self._h2d_done[slot].synchronize()          # the H2D of `capacity` frames ago has left the pinned slot (normally long ago)
         np.copyto(self._hv[lo:lo + crop.size], crop.reshape(-1) if crop.flags.c_contiguous else np.ascontiguousarray(crop).reshape(-1))
         with torch.cuda.device(self.device):
-            # (stream order protects the slot: the warp launches that read its previous occupant were enqueued earlier on this
-            #  stream; the pinned slot itself was last read by the H2D of `capacity` frames ago, long complete)
+            cur = torch.cuda.current_stream(self.device)
+            if self._warp_done is not None:
+                cur.wait_event(self._warp_done)         # a warp launched from another stream may still read the slot's old occupant
             self.dev[lo:lo + crop.size].copy_(self.host[lo:lo + crop.size], non_blocking=True)
+            if self._h2d_done[slot] is None:
+                self._h2d_done[slot] = torch.cuda.Event()
+            self._h2d_done[slot].record(cur)
         self.frames.append((tuple(info[:4]), crop.shape, slot))
         if len(self.frames) > self.capacity - 1:
             self.frames.pop(0)
@@ -367,7 +378,14 @@ class StreamingCropAligner:
             if x < 0 or y < 0 or x + shp[1] > int(w) or y + shp[0] > int(h):
                 raise ValueError("aligner: frame %d (%dx%d at %d,%d) does not fit the %dx%d canvas" % (i, shp[1], shp[0], x, y, int(w), int(h)))
         with torch.cuda.device(self.device):
+            cur = torch.cuda.current_stream(self.device)
+            for f in win:                                # crops pushed from another stream: their uploads come first
+                if self._h2d_done[f[2]] is not None:
+                    cur.wait_event(self._h2d_done[f[2]])
             al.launch_warps(self.dev, [f[2] * self.slot_bytes for f in win], shapes, diff, int(h), int(w), tfm, out)
+            if self._warp_done is None:
+                self._warp_done = torch.cuda.Event()
+            self._warp_done.record(cur)
         return t68, out
 
 

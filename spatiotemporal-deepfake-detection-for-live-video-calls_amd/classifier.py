@@ -181,9 +181,10 @@ class I3D8x8(_HipNetwork):
         super().__init__(i3d_r50_spec(num_frames=clip_size, crop=crop_size), precision)
         self.clip_size, self.imsize = clip_size, imsize
         # streams = 2: a batch of >= split_min_batch clips runs as two half-batches on two HIP streams (two engines).  The forward
-        # alternates between MFMA-bound and HBM-bound launches and between full and 77 %-full rounds of tiles; the launches of
-        # two independent half-batches fill some of each other's idle time (measured: B=16 +3 %, B=32 +4.6 % - DESIGN.md 7).
-        # Off by default (1): opt in with the argument or AF_MI355X_STREAMS=2.
+        # alternates between MFMA-bound and HBM-bound launches; the launches of two independent half-batches can fill some of each
+        # other's idle time.  Measured with the round-2 kernels: B=16 +2-3 %, B=32 +5 %; with the round-3 / round-4 kernels (whole
+        # rounds of persistent workgroups per launch) it is a LOSS at B=16 (driver's round-3 line: 3 047 against 3 121 clips/s) -
+        # DESIGN.md 7.  Off by default (1): opt in with the argument or AF_MI355X_STREAMS=2, and measure.
         self.streams = int(streams if streams is not None else os.environ.get("AF_MI355X_STREAMS", "1"))
         self.split_min_batch = 16
         self._side = {}
@@ -290,13 +291,25 @@ class LiveScorer:
                 self._scores = network.forward_clips_u8(self.clip, return_scores=True)["scores"]
         self._host = torch.empty(self._scores.shape, dtype=torch.float32, pin_memory=True)
 
-    def __call__(self, aligned_clip_u8: Optional[torch.Tensor] = None):
-        """aligned_clip_u8: (T,H,W,3) or (1,T,H,W,3) uint8 device tensor, or None when the window was written into ``self.clip``"""
-        if aligned_clip_u8 is not None:
-            self.clip.copy_(aligned_clip_u8.reshape(self.clip.shape), non_blocking=True)
-        self.graph.replay()
-        self._host.copy_(self._scores.float(), non_blocking=True)
-        torch.cuda.current_stream(self.clip.device).synchronize()
+    def __call__(self, aligned_clip_u8: Optional[torch.Tensor] = None, wait_for=None):
+        """aligned_clip_u8: (T,H,W,3) or (1,T,H,W,3) uint8 device tensor, or None when the window was written into ``self.clip``.
+        The replay runs on the CURRENT stream of the clip's device: whatever wrote ``self.clip`` (e.g.
+        ``StreamingCropAligner.align_last(out=scorer.clip[0])``) must have been enqueued on that stream, or be handed over as
+        ``wait_for`` (a ``torch.cuda.Event`` or ``torch.cuda.Stream`` the replay then waits on)."""
+        dev = self.clip.device
+        with torch.cuda.device(dev):                  # (a multi-GPU process: the caller's current device may be another one)
+            cur = torch.cuda.current_stream(dev)
+            if isinstance(wait_for, torch.cuda.Event):
+                cur.wait_event(wait_for)
+            elif isinstance(wait_for, torch.cuda.Stream):
+                cur.wait_stream(wait_for)
+            elif wait_for is not None:
+                raise TypeError("wait_for: a torch.cuda.Event or torch.cuda.Stream")
+            if aligned_clip_u8 is not None:
+                self.clip.copy_(aligned_clip_u8.reshape(self.clip.shape), non_blocking=True)
+            self.graph.replay()
+            self._host.copy_(self._scores.float(), non_blocking=True)
+            cur.synchronize()
         return self._host.numpy().copy()
 
 

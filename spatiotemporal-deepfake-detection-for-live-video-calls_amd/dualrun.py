@@ -353,7 +353,7 @@ class DualEncoderRGB(nn.Module):
         self.use_dat, self.domain_head, self.quality_head = False, None, None
         self._packed = None
         self._pe = {}
-        self._mask_checked = None              # (data_ptr, version, shape, device) of the last key_padding_mask that passed validation
+        self._mask_checked = None              # (tensor, version) of the last key_padding_mask that passed validation (a strong reference)
         self._side = None                      # side stream of the two-stream form (rgb_from_features=False)
 
     def _signature(self):
@@ -410,18 +410,20 @@ class DualEncoderRGB(nn.Module):
             valid = ~key_padding_mask.to(dev)
             lengths = valid.sum(dim=1).to(torch.int32)
             # the two checks read a flag back from the device, i.e. wait for everything enqueued before (a whole AltFreezing forward
-            # in the two-stream model): a mask tensor that passed them is not checked again until it is modified
-            # (an inference-mode tensor has no version counter: always checked)
-            key = None if key_padding_mask.is_inference() else (key_padding_mask.data_ptr(), key_padding_mask._version,
-                                                                tuple(key_padding_mask.shape), str(key_padding_mask.device))
-            if key is None or key != self._mask_checked:
+            # in the two-stream model): the mask TENSOR that passed them is not checked again until it is modified.  The module keeps
+            # a strong reference to it and compares identity + version counter: an address or a shape identifies no contents (a new
+            # mask built per step lands at the freed address of the last one with the same version), an object that is still alive
+            # and unmodified does.  (An inference-mode tensor has no version counter: always checked.)
+            seen = self._mask_checked
+            if (key_padding_mask.is_inference() or seen is None or seen[0] is not key_padding_mask
+                    or seen[1] != key_padding_mask._version):
                 prefix = torch.arange(T, device=dev).expand(B, T) < lengths.view(-1, 1)
                 if not bool((prefix == valid).all()):
                     raise ValueError("key_padding_mask must mark a suffix of every clip as padding (lengths_to_mask form)")
                 if bool((lengths == 0).any()):
                     raise ValueError("a clip without any valid frame: upstream's softmax over an all-masked row is NaN; "
                                      "build the mask with lengths_to_mask, which keeps frame 0")
-                self._mask_checked = key
+                self._mask_checked = None if key_padding_mask.is_inference() else (key_padding_mask, key_padding_mask._version)
             lengths = lengths.contiguous()
         clips = None
         if not self.rgb_from_features:

@@ -123,3 +123,34 @@ def test_streaming_aligner_equals_the_batch_call():
             assert (got.cpu().numpy() == want).all()
     with pytest.raises(ValueError):
         sal.align_last(12)                                       # only capacity - 1 frames stay resident
+
+
+def test_non_contiguous_crops_and_other_stream_push():
+    """Crops handed over as VIEWS of the camera frame (frame[y0:y1, x0:x1]: rows not contiguous) go through contiguous temporaries
+    inside the staging call - which must keep them alive until its copy threads have returned (round-3 advisor finding) - and give
+    the same clip as their contiguous copies, bit for bit; frames pushed to the streaming aligner from a side stream are ordered
+    in front of the warp by the slot events."""
+    g = load_npz("f8_aligner.npz")
+    rng = np.random.default_rng(11)
+    infos, images = _clip(rng, g, "t32_224")
+    views = []
+    for im in images:                                            # every crop as an interior view of a larger frame
+        frame = rng.integers(0, 256, size=(im.shape[0] + 7, im.shape[1] + 9, 3), dtype=np.uint8)
+        frame[3:3 + im.shape[0], 4:4 + im.shape[1]] = im
+        v = frame[3:3 + im.shape[0], 4:4 + im.shape[1]]
+        assert not v.flags.c_contiguous
+        views.append(v)
+    al = aligner.FasterCropAlignXRay(224)
+    want68, want = al(infos, images)
+    for _ in range(3):                                           # repeated: freed temporaries would be recycled by the allocator
+        got68, got = al(infos, views)
+        np.testing.assert_allclose(got68, want68, rtol=0, atol=0)
+        assert (got == want).all()
+    sal = aligner.StreamingCropAligner(224, capacity=40, max_crop_pixels=max(im.shape[0] * im.shape[1] for im in images))
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        for info, v in zip(infos, views):
+            sal.push(info, v)
+    got68, got = sal.align_last(32)                              # current stream != the stream the crops were uploaded on
+    torch.cuda.synchronize()
+    assert (got.cpu().numpy() == want).all()

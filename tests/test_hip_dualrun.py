@@ -141,6 +141,33 @@ def test_dual_rgb_vs_oracle_and_contract(dual_rgb):
         dualrun.DualEncoderRGB(36, 132, 2048)                                      # upstream's default ff_dim=768: 196 608-wide layers
 
 
+def test_mask_check_is_not_skipped_for_a_new_tensor_at_a_recycled_address(dual_rgb):
+    """The padding-mask validity check is remembered per mask TENSOR (identity + version), not per (address, shape): a fresh invalid
+    mask that the allocator places where the last valid one lived - what a caller who rebuilds the mask every step produces - must
+    still raise (outside inference mode, where tensors carry version counters and the cache is live)."""
+    g, sp, sd, net = dual_rgb
+    A, L, lengths = dualrun.synthetic_dual_inputs(4, sp, frames=8, seed=11)
+    V = torch.rand((4, 8, 2048), generator=torch.Generator().manual_seed(3))
+    A, L, V = A.cuda(), L.cuda(), V.cuda()
+    with torch.no_grad():
+        good = dualrun_oracle.lengths_to_mask(lengths, 8).cuda()
+        y0 = net(A, L, V, key_padding_mask=good)
+        y1 = net(A, L, V, key_padding_mask=good)                    # same live tensor, unmodified: the cached verdict applies
+        assert torch.equal(y0, y1)
+        shape = tuple(good.shape)
+        del good
+        bad = torch.zeros(shape, dtype=torch.bool, device="cuda")   # same shape, usually the freed block of `good`, one in-place write
+        bad[:, 0] = True                                            # padding first = not a suffix mask
+        with pytest.raises(ValueError, match="suffix"):
+            net(A, L, V, key_padding_mask=bad)
+        # ... and a mask edited in place after it passed is checked again
+        ok = dualrun_oracle.lengths_to_mask(lengths, 8).cuda()
+        net(A, L, V, key_padding_mask=ok)
+        ok[0, 0] = True; ok[0, 1] = False
+        with pytest.raises(ValueError, match="suffix"):
+            net(A, L, V, key_padding_mask=ok)
+
+
 def test_two_stream_model_as_one_unit(dual_rgb):
     """BASELINE config[3] shape: AltFreezing (shrunken clip, fp32) -> pooled 2048-vector -> DualEncoderRGB -> GatedMoE with the
     AltFreezing logit, everything on the device; each stage against its oracle."""

@@ -6,9 +6,13 @@ reference"):
   f32  : asserted at 2e-4 (exact-fp32 MFMA path; measures 1.5e-6)
   f16  : asserted at 1e-3 - the north-star tolerance (measures 2.5e-4..3.2e-4); the reference's own GPU deployment
          precision (torch.amp.autocast fp16, test/af_realtime.py:70,84)
-  bf16 : BF16_TOL below - the measured bound with a little margin.  bf16 (8 significant bits) does NOT reliably meet
-         1e-3: the reference itself under CPU bf16 autocast is 4.4e-3..1e-2 off.  Documented, not hidden.
-On the "hot" checkpoint (|logit| 18..33, tests/golden/f1b_logits.json) the 16-bit bounds are relative to |logit|.
+  bf16 : BF16_TOL = 3e-3 (round 4; 1e-2 before): the measured bound - 9e-4..1.6e-3 on the golden clips and at B = 16 - with a
+         margin under 2x, so that a regression of the kernels shows.  bf16 (8 significant bits of weight) does NOT reliably meet
+         1e-3: the reference itself under CPU bf16 autocast is 4.4e-3..1e-2 off.  Documented, not hidden; f16 is
+         the 16-bit mode that meets the north-star tolerance.
+On the "hot" checkpoint (|logit| 18..33, tests/golden/f1b_logits.json) the 16-bit bounds are relative to |logit|: bf16 7e-3
+(measured 4.8e-3; 1.2e-2 before).  The shrunken 8-frame 64 x 64 network of the all-dtypes tests measures 3.7e-3 in bf16 (different
+weights, three clips) and is asserted at 6e-3.
 """
 import os
 import sys
@@ -26,9 +30,9 @@ from af_mi355x import synth  # noqa: E402
 from af_mi355x.classifier import Classifier  # noqa: E402
 
 pytestmark = pytest.mark.gpu
-BF16_TOL = 1e-2
+BF16_TOL = 3e-3
 LOGIT_TOL = {"f32": 2e-4, "f16": 1e-3, "bf16": BF16_TOL}
-REL_TOL = {"f32": 1e-5, "f16": 1.5e-3, "bf16": 1.2e-2}       # hot checkpoint: |d| <= REL_TOL * |logit|
+REL_TOL = {"f32": 1e-5, "f16": 1.5e-3, "bf16": 7e-3}       # hot checkpoint: |d| <= REL_TOL * |logit|
 
 
 @pytest.fixture(scope="module")
@@ -213,7 +217,7 @@ def test_small_network_vs_oracle_all_dtypes():
     u8 = synth.synthetic_clips_u8(3, seed=9, kind="smooth", num_frames=clip_size, size=size)
     x = synth.normalize_like_callers(u8)
     want = oracle.forward(sd, x, num_frames=clip_size, crop=size)
-    for dtype, tol in (("f32", 1e-4), ("f16", 1e-3), ("bf16", 1e-2)):
+    for dtype, tol in (("f32", 1e-4), ("f16", 1e-3), ("bf16", 6e-3)):
         clf = Classifier(clip_size=clip_size, precision=dtype, crop_size=size)
         clf.network.load_state_dict(sd)
         clf = clf.to("cuda").eval()
@@ -238,7 +242,7 @@ def test_non_finite_pixel_gives_nan_logit_like_reference(nan):
     x[1, 2, 3, 17, 40] = nan
     want = oracle.forward(sd, x, num_frames=clip_size, crop=size)
     assert torch.isnan(want[1]).all() and torch.isfinite(want[[0, 2]]).all()
-    for dtype, tol in (("f32", 1e-4), ("f16", 1e-3), ("bf16", 1e-2)):
+    for dtype, tol in (("f32", 1e-4), ("f16", 1e-3), ("bf16", 6e-3)):
         clf = Classifier(clip_size=clip_size, precision=dtype, crop_size=size)
         clf.network.load_state_dict(sd)
         clf = clf.to("cuda").eval()

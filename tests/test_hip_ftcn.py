@@ -1,7 +1,7 @@
 """GPU: the reference's second plugin, FTCN-TT, on the HIP kernels against the golden
 logits / stage samples / head known-answer produced by the reference plugin itself (tests/golden/f6_ftcn*), plus
 the plugin-specific kernels against the CPU oracle on small cases.
-Tolerances: f32 2e-4 (north star 1e-3), f16 1e-3 (= the north star), bf16 1e-2 (measured bound + margin; bf16 does not reliably meet 1e-3) on an O(1) logit - as for the other networks."""
+Tolerances: f32 2e-4 (north star 1e-3), f16 1e-3 (= the north star), bf16 2e-3 (measured 4.5e-4..5.1e-4: the fp32 head helps; 1e-2 before round 4) on an O(1) logit."""
 import ctypes as C
 import os
 import sys
@@ -34,7 +34,7 @@ def _clip(c):
     return synth.normalize_like_callers(u8).cuda()
 
 
-@pytest.mark.parametrize("dtype,tol", [("f32", 2e-4), ("f16", 1e-3), ("bf16", 1e-2)])
+@pytest.mark.parametrize("dtype,tol", [("f32", 2e-4), ("f16", 1e-3), ("bf16", 2e-3)])
 def test_ftcn_logits_match_reference(ftcn_weights, dtype, tol):
     g, sd = ftcn_weights
     net = FtcnTT8x8(precision=dtype)
