@@ -105,6 +105,14 @@ template <> struct MmaAsm<AF_F16> {
         asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
     }
 };
+// The accumulators of an asm-MFMA loop must be ordinary live registers BEFORE the loop: left to itself hipcc sinks "acc = 0" to the
+// first use (a peeled first iteration: v_mov zero, zero, MFMA, v_mov ...), i.e. it writes an MFMA's C operand with vector moves
+// one or two instructions in front of the asm MFMA that reads it - and reuses a fragment register the previous MFMA is still
+// reading for the next tile's zeros - without the wait states its hazard recogniser would give its own MFMAs (whole-network f16
+// logits moved by 2e-3, differently from run to run).  acc_live() makes the zeroed tile opaque (no rematerialisation, one register
+// set for the whole loop); mfma_operands_settled() = the wait states between the last vector write of an operand and the first MFMA.
+__device__ __forceinline__ void acc_live(f32x4& c) { asm volatile("" : "+v"(c)); }
+__device__ __forceinline__ void mfma_operands_settled() { asm volatile("s_nop 3" ::: "memory"); }
 __device__ __forceinline__ void mfma_drain() { asm volatile("s_nop 15\n\ts_nop 7" ::: "memory"); }   // > the 8-pass MFMA's 12 wait states
 // What rides behind MFMA t of a K-step's second MFMA group: NP DMA pieces and NR fragment reads dealt out one per MFMA in the
 // pattern piece, read, read, piece, ... (a piece first: the DMA of the stage two ahead wants all the lead it can get; the reads

@@ -274,7 +274,11 @@ __global__ __launch_bounds__(WN * WM * KS * 64, MINW) void conv_igemm_kernel(con
                 st = (st == 2) ? 0 : st + 1;
             }
         }
+#ifdef AF_NO_ASM_IGEMM
+    } else if constexpr (false) {
+#else
     } else if constexpr (DT != AF_F32 && !DUAL && !(LEAN || NKK == 1 || TM < 4)) {
+#endif
         // ---- MFMA-bound variants, 16-bit operands, one input (round 4; the projection blocks' second K segment doubles the
         // descriptors and offsets the DMA issue selects from - 106 scalar registers and spills next to the DMA - and keeps the builtin loop): the K loop as asm statements, issued in program order - MFMAs
         // accumulating in place, LDS fragment reads hipcc does not count, LDS-DMA, the kernel's own waits (af_common.h) - on the
@@ -320,14 +324,24 @@ __global__ __launch_bounds__(WN * WM * KS * 64, MINW) void conv_igemm_kernel(con
         if (S >= NSTAGE) wait_vmcnt<(NSTAGE - 1) * PER_WAVE>(); else if (S == 2) wait_vmcnt<PER_WAVE>(); else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         static_for<NR>([&](auto r) { frag_read(a0, b0, wb[0], xb[0], r); });
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j) acc_live(acc[i][j]);
+        mfma_operands_settled();
         const bool late = wave >= 4;
         int stoff = 0;                                             // ring slot of stage s (bytes)
+        // (No LDS read is left pending across the loop's back edge - the wait for the look-ahead reads closes the body - and the
+        //  loop is neither unrolled nor peeled: hipcc reconciles the register assignment of a peeled first iteration with the
+        //  steady loop by copying every live register, fragments whose data has not landed included.  tests/test_host_cpu.py
+        //  lints the generated code for both.)
+        wait_lgkmcnt<0>();
+        pin_half(a0, b0);
+#pragma nounroll
         for (int s = 0; s < S; ++s) {
             const bool laststep = s + 1 == S;
             const int stnext = stoff == (NSTAGE - 1) * STAGE_BYTES ? 0 : stoff + STAGE_BYTES;
             // first group: MFMA(a0, b0) [stage s, k-half 0] while the fragments of k-half 1 come in
-            wait_lgkmcnt<0>();
-            pin_half(a0, b0);
             // what must have landed in front of the barrier: stage s + 1.  Two slots: the only stage in flight.  Three slots: the
             // pieces of stage s + 2 (or their empty stand-ins) were issued behind it in the previous step and stay in flight; at
             // K-step 0 the younger operations are the prologue's (stage 2 if the layer has one).
@@ -380,9 +394,10 @@ __global__ __launch_bounds__(WN * WM * KS * 64, MINW) void conv_igemm_kernel(con
             });
             if (refill) advance();
             stoff = stnext;
+            wait_lgkmcnt<0>();                                     // a0 / b0 of the next step (read under this group) are back
+            pin_half(a0, b0);
         }
         wait_vmcnt<0>();                                           // (the empty stand-in pieces of the last steps write zeros into the ring: the epilogue reuses it)
-        wait_lgkmcnt<0>();                                         // (the last step's look-ahead reads land in registers the epilogue reuses)
         mfma_drain();                                              // the accumulators are read by ordinary vector code from here on
     } else {
         // MFMA-bound variants, fp32 (four exact-fp32 MFMAs per chunk) and the two-input projection blocks: software-pipelined by k-HALVES.  The fragments of a half are read from LDS while
@@ -513,6 +528,50 @@ __global__ __launch_bounds__(WN * WM * KS * 64, MINW) void conv_igemm_kernel(con
 #pragma unroll
             for (int j = 0; j < TM; ++j) acc[i][j] += red[(wsub * TN * TM + i * TM + j) * 64 + lane];
         patch_off = WN * WM * TN * TM * 64 * 4;        // patches live above the reduction buffer
+    }
+    // ---- 16-bit layers without a residual, a fused pool or a K split (every `a` / `b` conv and the projection blocks): BN + ReLU + the
+    // one rounding happen in the accumulator layout and the transposition patch holds 16-bit values - half the LDS traffic of the
+    // fp32 patch below, no conversions behind it (conv133g's epilogue: 7 k against 10.7 k cycles per 28-tile wave, in-kernel stamps).
+    // The residual layers keep the fp32 patch: their sum is formed in fp32 on whole rows before the one rounding; so do the small
+    // tiles that share a CU three or more at a time (<= 80 registers: no room for the BN parameters of a whole sub-tile).
+    if constexpr (DT != AF_F32 && !SPLITK && KS == 1 && !LEAN) {
+        if (a.tpool == 0 && !a.res) {
+            typedef typename E::type OT;
+            constexpr int PROW16 = WTN + 8;            // patch row stride in elements
+            OT* patch16 = reinterpret_cast<OT*>(smem) + wsub * (16 * PROW16);
+            constexpr int LPR16 = WTN / 8, RPI16 = 64 / LPR16;
+            const int rr16 = lane / LPR16, cc16 = (lane % LPR16) * 8;
+            const int chb = tile_n * BN + wn * WTN;
+            f32x4 sc[TN], sf[TN];
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                sc[i] = *reinterpret_cast<const f32x4*>(a.scale + chb + i * 16 + fg * 4);
+                sf[i] = *reinterpret_cast<const f32x4*>(a.shift + chb + i * 16 + fg * 4);
+            }
+            const float lo = a.relu ? 0.f : -__builtin_inff();     // max(v, lo): ReLU or nothing, NaN kept either way, no branch
+#pragma unroll
+            for (int j = 0; j < TM; ++j) {
+#pragma unroll
+                for (int i = 0; i < TN; ++i) {
+                    f32x4 v = acc[i][j] * sc[i] + sf[i];
+                    v[0] = max_nan(v[0], lo); v[1] = max_nan(v[1], lo); v[2] = max_nan(v[2], lo); v[3] = max_nan(v[3], lo);
+                    Vec4<DT>::store(reinterpret_cast<char*>(patch16 + frow * PROW16 + i * 16 + fg * 4), v);
+                }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int it = 0; it < 16 / RPI16; ++it) {
+                    const int row = it * RPI16 + rr16;
+                    const long long m = m0 + wm * WTM + j * 16 + row;
+                    const u32x4 o = *reinterpret_cast<const u32x4*>(patch16 + row * PROW16 + cc16);
+                    if (m < a.M && (BMR == BM || wm * WTM + j * 16 + row < BMR) && chb + cc16 < a.Cout)
+                        __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(a.out + (m * a.out_ld + chb + cc16) * ES));
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            AF_STAMP(3); AF_STAMP(7);
+            AF_STAMP_FLUSH;
+            return;
+        }
     }
     constexpr int PROW = WTN + 4;                      // patch row stride in floats (pad: conflict-free b128 writes)
     constexpr int HALVES = TM % 4 == 0 && TM >= 8 ? 4 : TM % 2 == 0 ? 2 : TM;   // the patch holds a slice of the sub-tile at a time (LDS footprint)

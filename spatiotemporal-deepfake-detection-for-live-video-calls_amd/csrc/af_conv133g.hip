@@ -212,6 +212,11 @@ __global__ __launch_bounds__(512, 2) void conv133g_kernel(const C133GArgs a) {
     wait_vmcnt<0>();                                   // (the weight stages went first: they are in long before the patch)
     __builtin_amdgcn_s_barrier();
     const bool late = a.stagger && wave >= 4;
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) acc_live(acc[i][j]);
+    mfma_operands_settled();
     {
         constexpr int H1 = 3 * NTH / 4;                                    // MFMAs of a LATE wave's first group in front of its barrier
         static_assert(NR + RW + 1 <= NTH, "a DMA piece or a read per MFMA of the second group");
@@ -221,6 +226,11 @@ __global__ __launch_bounds__(512, 2) void conv133g_kernel(const C133GArgs a) {
             const unsigned wsb = w_addr(0, 0), xsb = x_addr(0, 0, 0);
             static_for<NR>([&](auto r) { frag_read(a0, b0, wsb, xsb, r); });
         }
+        // (no LDS read stays pending across a tap body's end, and the slab loop is neither unrolled nor peeled: af_conv.hip's K loop
+        //  has the reasons)
+        wait_lgkmcnt<0>();
+        pin_half(a0, b0);
+#pragma nounroll
         for (int slab = 0; slab < nslabs; ++slab) {
             const bool lastslab = slab + 1 == nslabs;
             const int wsl_c = w_slab_offset(slab), wsl_n = w_slab_offset(lastslab ? slab : slab + 1);
@@ -238,8 +248,6 @@ __global__ __launch_bounds__(512, 2) void conv133g_kernel(const C133GArgs a) {
                 asm volatile("" : "+s"(sh), "+s"(nsh));
                 // first group: MFMA(a0, b0) [stage s, k-half 0] while the fragments of k-half 1 come in
                 const unsigned wsb1 = w_addr(stoff, 1), xsb1 = x_addr(bufc, sh, 1);
-                wait_lgkmcnt<0>();                     // a0 / b0 (read under the previous group) are back
-                pin_half(a0, b0);
                 // (the last K-step runs the same instruction stream with its barrier, look-ahead reads and DMA switched off: a
                 //  separate tail would meet this path in 112 accumulator phis)
                 const bool laststep = tap == 8 && lastslab;
@@ -284,6 +292,8 @@ __global__ __launch_bounds__(512, 2) void conv133g_kernel(const C133GArgs a) {
                     else if constexpr (slot != kNoSlot) { if (refill) issue_w_piece(stoff, wsoff, slot - 1); }
                 });
                 stoff = stnext;
+                wait_lgkmcnt<0>();                     // a0 / b0 of the next step (read under this group) are back
+                pin_half(a0, b0);
             });
             const int tb = bufc; bufc = bufn; bufn = tb;
         }

@@ -303,6 +303,20 @@ def _device_asm(src):
     return out.stdout.decode()
 
 
+_ASM_CACHE = {}
+
+
+def _all_device_asm():
+    """{file: gfx950 assembly} of every kernel source, compiled once per test session (~1 min on 6 threads)"""
+    if not _ASM_CACHE:
+        from concurrent.futures import ThreadPoolExecutor
+        csrc = os.path.join(ROOT, "spatiotemporal-deepfake-detection-for-live-video-calls_amd", "csrc")
+        files = sorted(f for f in os.listdir(csrc) if f.endswith(".hip"))
+        with ThreadPoolExecutor(max_workers=6) as ex:
+            _ASM_CACHE.update(zip(files, ex.map(lambda f: _device_asm(os.path.join(csrc, f)), files)))
+    return _ASM_CACHE
+
+
 def _regs_of(text):
     regs = set()
     for m in re.finditer(r"\bv\[(\d+):(\d+)\]|\bv(\d+)\b", text):
@@ -320,11 +334,7 @@ def test_hand_counted_vmcnt_kernels_have_no_spills_and_no_early_use_of_uncounted
     (`bload16_nt_uncounted` / `gload16_uncounted`: a buffer / global load inside an ASMSTART block, without `lds`) and the
     next `s_waitcnt vmcnt` in straight-line code, no instruction reads or writes its destination registers (a phi copy or
     v_mov of a pending register would read stale data)."""
-    from concurrent.futures import ThreadPoolExecutor
-    csrc = os.path.join(ROOT, "spatiotemporal-deepfake-detection-for-live-video-calls_amd", "csrc")
-    files = sorted(f for f in os.listdir(csrc) if f.endswith(".hip"))
-    with ThreadPoolExecutor(max_workers=6) as ex:
-        asms = dict(zip(files, ex.map(lambda f: _device_asm(os.path.join(csrc, f)), files)))
+    asms = _all_device_asm()
     n_kernels = n_loads = 0
     for f, asm in asms.items():
         names = re.findall(r"^\s*\.name:\s+(\S+)$", asm, re.M)
@@ -375,6 +385,57 @@ def test_hand_counted_vmcnt_kernels_have_no_spills_and_no_early_use_of_uncounted
                     f, sorted(hit), i + 1, t, j + 1, u)
     assert n_counted >= 10, n_counted                              # ... including the kernels with counted waits
     assert n_kernels >= 40 and n_loads >= 8, (n_kernels, n_loads)   # the lint saw the kernels / loads it is meant for
+
+
+def test_asm_statement_mfmas_and_lds_reads_are_not_crowded_by_compiler_code():
+    """Round 4: the MFMA-bound K loops issue their MFMAs and LDS fragment reads as asm statements (af_common.h: MmaAsm,
+    lds_read16_uncounted).  hipcc pads the hazards of its own MFMAs and counts its own LDS reads; around an asm statement it does
+    neither, so the generated code is checked instead:
+    (1) no vector-ALU instruction writes an operand register of an asm MFMA within the two instructions in front of it (what hipcc
+        made of "acc = 0" before acc_live(): v_mov zero, zero, MFMA - whole-network f16 logits moved by 2e-3, run to run);
+    (2) between an asm ds_read_b128 and the next s_waitcnt that names lgkmcnt on the fall-through path, nothing mentions its
+        destination registers (a copy or a reuse of a fragment register whose data has not landed)."""
+    n_mfma = n_reads = 0
+    for f, asm in _all_device_asm().items():
+        lines = [ln.split(";")[0].strip() if not ln.strip().startswith(";;#") else ln.strip() for ln in asm.splitlines()]
+        in_asm = False
+        hist = []                                                  # the last instructions: (inside an asm block?, text)
+        for i, t in enumerate(lines):
+            if t.startswith(";;#ASMSTART"):
+                in_asm = True
+                continue
+            if t.startswith(";;#ASMEND"):
+                in_asm = False
+                continue
+            if not t or t.startswith(".") or t.endswith(":"):
+                if t.endswith(":") and t.startswith("_Z"):
+                    hist = []
+                continue
+            if in_asm and t.startswith("v_mfma"):
+                n_mfma += 1
+                srcs = _regs_of(t.split(None, 1)[1].split(",", 1)[1])         # A, B, C (C = the destination registers)
+                for was_asm, u in hist[-2:]:
+                    if u.startswith("v_") and not u.startswith(("v_mfma", "v_cmp")):
+                        hit = _regs_of(u.split(None, 1)[1].split(",")[0]) & srcs
+                        assert not hit, "%s: v%s written by `%s` right in front of the asm MFMA `%s`" % (f, sorted(hit), u, t)
+            if in_asm and t.startswith("ds_read_b128"):
+                n_reads += 1
+                dest = _regs_of(t.split(None, 1)[1].split(",")[0])
+                for j in range(i + 1, len(lines)):
+                    u = lines[j]
+                    if not u or u.startswith((".", ";;#")) or u.endswith(":"):
+                        continue
+                    if u.startswith("s_waitcnt") and "lgkmcnt" in u:
+                        break
+                    if u.startswith(("s_branch", "s_endpgm", "s_setpc")):
+                        break
+                    if u.startswith("ds_read_b128") and not (dest & _regs_of(u)):
+                        continue
+                    hit = dest & _regs_of(u)
+                    assert not hit, "%s: v%s is the destination of a pending asm LDS read (line %d: %s) but line %d touches it: %s" % (
+                        f, sorted(hit), i + 1, t, j + 1, u)
+            hist.append((in_asm, t))
+    assert n_mfma >= 1000 and n_reads >= 500, (n_mfma, n_reads)     # the lint saw the loops it is meant for
 
 
 def test_stage_rows_host_helper_matches_numpy():
