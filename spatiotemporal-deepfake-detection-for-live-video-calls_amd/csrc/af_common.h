@@ -143,6 +143,10 @@ int conv133_run(const af_conv_desc* d, const void* in, const void* w_packed, con
 bool conv133g_applies(const af_conv_desc* d, const void* residual, int out_ld);
 int conv133g_run(const af_conv_desc* d, const void* in, const void* w_packed, const float* scale, const float* shift,
                  void* out, int out_ld, hipStream_t stream);
+// ... and its TEMPORAL mode: 3x1x1 convs into 128 / 256 channels (s3 / s4 `a` convs): (T + 2) x P patch, three taps share it
+bool conv311g_applies(const af_conv_desc* d, const void* residual, int out_ld);
+int conv311g_run(const af_conv_desc* d, const void* in, const void* w_packed, const float* scale, const float* shift,
+                 void* out, int out_ld, hipStream_t stream);
 bool conv133g_fused_applies(const af_conv_desc* db, const af_conv_desc* dc, int out_ld);
 int conv133g_fused_run(const af_conv_desc* db, const void* in, const void* wb, const float* scale_b, const float* shift_b,
                        const af_conv_desc* dc, const void* wc, const float* scale_c, const float* shift_c, const void* residual,

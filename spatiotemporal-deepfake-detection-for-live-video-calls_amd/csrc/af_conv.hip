@@ -728,7 +728,7 @@ static int launch(const ConvArgs& a, hipStream_t stream) {
 // output: half-height tiles with a trimmed ring so several workgroups share a CU and overlap each
 // other's load / store phases.
 enum { VAR_128x256 = 0, VAR_64x256 = 1, VAR_128x128 = 2, VAR_64x128 = 3, VAR_C133 = 4, VAR_128x128_R2 = 5, VAR_256x256 = 6,
-       VAR_128x512 = 7, VAR_C311 = 8, VAR_SMALL = 9, VAR_C111 = 10, VAR_C133G = 11, VAR_256x224 = 12, VAR_COUNT = 13 };
+       VAR_128x512 = 7, VAR_C311 = 8, VAR_SMALL = 9, VAR_C111 = 10, VAR_C133G = 11, VAR_256x224 = 12, VAR_C311G = 13, VAR_COUNT = 14 };
 static const char* const kVariantNames[] = {"conv_igemm<BN=128,BM=256>", "conv_igemm<BN=64,BM=256>",
                                             "conv_igemm<BN=128,BM=128>", "conv_igemm<BN=64,BM=128>",
                                             "conv133_c64<weights in registers>", "conv_igemm<BN=128,BM=128>",
@@ -737,7 +737,8 @@ static const char* const kVariantNames[] = {"conv_igemm<BN=128,BM=256>", "conv_i
                                             "conv_small<direct-gather MFMA, narrow layers>",
                                             "conv111<persistent stream, weights in registers>",
                                             "conv133g<frame-resident halo patch, 9 taps share it>",
-                                            "conv_igemm<BN=256,BM=224>"};
+                                            "conv_igemm<BN=256,BM=224>",
+                                            "conv311g<clip-resident (T + 2) x P patch, 3 taps share it>"};
 
 static int pick_variant(int cout, int cin, int taps, int dtype, long long M, int cin2 = 0, int pooled = 0) {
     const int ksteps = (taps * cin + cin2) / (dtype == AF_F32 ? 32 : 64);
@@ -869,6 +870,7 @@ extern "C" int af_conv_variant(const af_conv_desc* d, const af_conv_desc* d2) {
     if (af::conv_small_applies(d, d2, nullptr, 0)) return af::VAR_SMALL;
     if (!d2 && af::conv133_applies(d, nullptr, 0)) return af::VAR_C133;
     if (!d2 && af::conv133g_applies(d, nullptr, 0)) return af::VAR_C133G;
+    if (!d2 && af::conv311g_applies(d, nullptr, 0)) return af::VAR_C311G;
     if (!d2 && af::conv311_applies(d, nullptr, 0)) return af::VAR_C311;
     if (af::conv111_applies(d, d2, nullptr, 0)) return af::VAR_C111;
     const int bk = d->dtype == AF_F32 ? 32 : 64;
@@ -925,6 +927,8 @@ static int conv_common(const af_conv_desc* d, const void* in, const void* w_pack
         return conv133_run(d, in, w_packed, scale, shift, out, (hipStream_t)stream);
     if (!small && !d2 && conv133g_applies(d, residual, out_ld))
         return conv133g_run(d, in, w_packed, scale, shift, out, out_ld, (hipStream_t)stream);
+    if (!small && !d2 && conv311g_applies(d, residual, out_ld))
+        return conv311g_run(d, in, w_packed, scale, shift, out, out_ld, (hipStream_t)stream);
     if (!small && !d2 && conv311_applies(d, residual, out_ld))
         return conv311_run(d, in, w_packed, scale, shift, out, out_ld, (hipStream_t)stream);
 

@@ -67,7 +67,7 @@ struct C133GArgs {
 #endif
 };
 
-template <int DT, int WN, int WM, int MT, bool FUSEC, int MAXP, int NSLOT>
+template <int DT, int WN, int WM, int MT, bool FUSEC, int MAXP, int NSLOT, bool TEMPORAL>
 __global__ __launch_bounds__(512, 2) void conv133g_kernel(const C133GArgs a) {
     typedef Elem<DT> E;
     typedef typename E::type OT;
@@ -78,6 +78,18 @@ __global__ __launch_bounds__(512, 2) void conv133g_kernel(const C133GArgs a) {
     constexpr int WSTAGE = BN * 128;                   // bytes of a weight stage ([BN][64 k])
     // MAXP: patch DMA pieces per wave (patch rows <= 64 MAXP; one piece per tap, so <= 9: 576 rows)
     constexpr int PROW = 64 + 8;                       // epilogue patch row stride (elements)
+    // TEMPORAL (round 4): the same kernel for 3x1x1 / stride 1 / pad (1,0,0) convs (the `a` convs of s3 / s4; reference
+    // resnet_helper.py:267-281).  Work unit = (clip, P consecutive pixels, all T frames); the patch of a K slab is (T + 2) x P rows
+    // (row j = frame j / P - 1 of pixel j % P; the two padding frames are out-of-range lanes), a tap is the row shift dt * P, and
+    // WM x MT x 16 = T x P positions are all real.  Three taps share a patch where the generic kernel fetched the tile per tap.
+    constexpr int NTAPS = TEMPORAL ? 3 : 9;
+    // Patch pieces a K-step carries: the next slab's patch rides on this slab's steps.  Every piece the next slab's FIRST step reads
+    // must be issued one step before this slab's last (whose wait + barrier then cover it; the look-ahead reads of the next slab
+    // are issued inside the last step).  Spatial: nine pieces on nine steps - piece 8 is patch rows 512.., which tap 0 never reads;
+    // temporal: every tap reads the whole patch, so the pieces ride on the first NTAPS - 1 steps.
+    constexpr int PSTEPS = TEMPORAL ? NTAPS - 1 : NTAPS;
+    constexpr int PPS = (MAXP + PSTEPS - 1) / PSTEPS;
+    static_assert(!(TEMPORAL && FUSEC) && NSLOT <= NTAPS, "temporal mode: no fused c conv; the prologue's stages are taps of slab 0");
 
     extern __shared__ uint4 smem[];
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
@@ -89,14 +101,14 @@ __global__ __launch_bounds__(512, 2) void conv133g_kernel(const C133GArgs a) {
     const int pbytes = a.prows * 128;
     const unsigned ring0 = lds0 + 2 * pbytes;
 
-    // ---- work unit: (frame, band of R output rows)
+    // ---- work unit: (frame, band of R output rows); TEMPORAL: (clip = `frame`, chunk of R = P pixels starting at pixel h0)
     const int unit = blockIdx.x;
     const int frame = unit / a.upf, h0 = (unit - frame * a.upf) * a.R;
-
+    const int HW = a.H * a.W;
     // ---- producers.  Weights: thread (lrow = tid >> 3, slot = tid & 7) fetches chunk slot ^ (lrow & 7) of weight rows
     // lrow + 64 i; the K-step's (tap, slab) offset goes in an SGPR.
     const int lrow = tid >> 3, wchunk = (tid & 7) ^ (lrow & 7);
-    const long long Kw = 9LL * a.kt * a.Cin;                           // weight row length (elements)
+    const long long Kw = (long long)NTAPS * a.kt * a.Cin;              // weight row length (elements; TEMPORAL: kt is a tap, a.kt = 1)
     const i32x4 wdesc = make_desc(a.w);
     const unsigned woff = (unsigned)((lrow * Kw + wchunk * 8) * 2);    // piece i: + 64 i weight rows (added to the scalar offset)
     const int wpiece_bytes = (int)(64 * Kw * 2);
@@ -108,7 +120,8 @@ __global__ __launch_bounds__(512, 2) void conv133g_kernel(const C133GArgs a) {
     // frames early, dt advances by whole frames in the SGPR offset
     const int pt = a.kt >> 1, tclip = frame % a.T;
     const int frame_bytes = a.H * a.W * a.Cin * 2;                     // < 2^29 (host-checked)
-    const i32x4 xdesc = make_desc(a.in + ((((long long)frame - pt) * a.H + h0 - 1) * a.W) * a.Cin * 2);
+    const i32x4 xdesc = make_desc(TEMPORAL ? a.in + ((((long long)frame * a.T - 1) * HW + h0) * a.Cin) * 2
+                                           : a.in + ((((long long)frame - pt) * a.H + h0 - 1) * a.W) * a.Cin * 2);
     unsigned poff[MAXP];                               // (filled in behind the first weight DMAs, below)
     // patch piece i of this wave (rows 8 (wave + 8 i) ..) of K slab (frame offset + channel slab = `soff`) into patch buffer at `bufoff`
     auto patch_slab_offset = [&](int ks, bool& inclip) {
@@ -124,7 +137,7 @@ __global__ __launch_bounds__(512, 2) void conv133g_kernel(const C133GArgs a) {
     // [Cout][kt * 9][Cin]: offset inside a weight row = w_slab_offset(ks) + tap * Cin * 2
     auto w_slab_offset = [&](int ks) {
         const int dt = (ks >= a.kslabs) + (ks >= 2 * a.kslabs), cs = ks - dt * a.kslabs;
-        return __builtin_amdgcn_readfirstlane((dt * 9 * a.Cin + cs * 64) * 2);
+        return __builtin_amdgcn_readfirstlane((dt * NTAPS * a.Cin + cs * 64) * 2);
     };
     const int tap_bytes = a.Cin * 2;
     auto issue_w_piece = [&](int stoff, int soff, int i) {
@@ -152,10 +165,19 @@ __global__ __launch_bounds__(512, 2) void conv133g_kernel(const C133GArgs a) {
 
 #pragma unroll
     for (int i = 0; i < MAXP; ++i) {
-        const int q = (wave + 8 * i) * 8 + drow - 1;
-        const int r = (int)(((float)q + 0.5f) * a.inv_wp), c = q - r * WP;
-        const bool ok = q >= 0 && r < a.R + 2 && c >= 1 && c <= a.W && (unsigned)(h0 - 1 + r) < (unsigned)a.H;
-        poff[i] = ok ? (unsigned)(((r * a.W + (c - 1)) * a.Cin) * 2 + pchunk * 16) : kOutOfRange;
+        if (TEMPORAL) {
+            // LDS row j = (frame tf = j / P of the padded clip, pixel q = j % P) <-> input (n, tf - 1, h0 + q); the descriptor
+            // starts one frame early
+            const int j = (wave + 8 * i) * 8 + drow;
+            const int tf = (int)(((float)j + 0.5f) * a.inv_wp), q = j - tf * a.R;
+            const bool ok = tf >= 1 && tf <= a.T && h0 + q < HW;
+            poff[i] = ok ? (unsigned)((((long long)tf * HW + q) * a.Cin) * 2 + pchunk * 16) : kOutOfRange;
+        } else {
+            const int q = (wave + 8 * i) * 8 + drow - 1;
+            const int r = (int)(((float)q + 0.5f) * a.inv_wp), c = q - r * WP;
+            const bool ok = q >= 0 && r < a.R + 2 && c >= 1 && c <= a.W && (unsigned)(h0 - 1 + r) < (unsigned)a.H;
+            poff[i] = ok ? (unsigned)(((r * a.W + (c - 1)) * a.Cin) * 2 + pchunk * 16) : kOutOfRange;
+        }
     }
     {
         bool in0;
@@ -219,7 +241,7 @@ __global__ __launch_bounds__(512, 2) void conv133g_kernel(const C133GArgs a) {
     mfma_operands_settled();
     {
         constexpr int H1 = 3 * NTH / 4;                                    // MFMAs of a LATE wave's first group in front of its barrier
-        static_assert(NR + RW + 1 <= NTH, "a DMA piece or a read per MFMA of the second group");
+        static_assert(NR + RW + PPS <= NTH, "a DMA piece or a read per MFMA of the second group");
         int stoff = 0;                                                     // ring slot of the current step (bytes): (s % NSLOT) * WSTAGE
         int bufc = 0, bufn = pbytes;                                       // patch buffers of this slab / the next one
         {
@@ -239,18 +261,18 @@ __global__ __launch_bounds__(512, 2) void conv133g_kernel(const C133GArgs a) {
             bool in1;
             const int ps1 = patch_slab_offset(lastslab ? slab : slab + 1, in1);
             const bool pp = !lastslab;
-            static_for<9>([&](auto tapc) {
-                constexpr int tap = tapc, dh = tap / 3, dw = tap % 3, ntap = (tap + 1) % 9, ndh = ntap / 3, ndw = ntap % 3;
-                constexpr int t2 = (tap + NSLOT) % 9;                      // the tap of stage s + NSLOT, which refills this step's slot
-                // (the row shifts pass through an empty asm: hipcc otherwise hoists the fragment addresses of all nine bodies out of
-                //  the slab loop and spills to keep them)
-                int sh = dh * WP + dw, nsh = ndh * WP + ndw;
+            static_for<NTAPS>([&](auto tapc) {
+                constexpr int tap = tapc, ntap = (tap + 1) % NTAPS;
+                constexpr int t2 = (tap + NSLOT) % NTAPS;                  // the tap of stage s + NSLOT, which refills this step's slot
+                // row shift of a tap: spatial (dh, dw) -> dh * WP + dw; temporal dt -> dt * P.  (The shifts pass through an empty
+                // asm: hipcc otherwise hoists the fragment addresses of all unrolled bodies out of the slab loop and spills to keep them.)
+                int sh = TEMPORAL ? tap * a.R : (tap / 3) * WP + tap % 3, nsh = TEMPORAL ? ntap * a.R : (ntap / 3) * WP + ntap % 3;
                 asm volatile("" : "+s"(sh), "+s"(nsh));
                 // first group: MFMA(a0, b0) [stage s, k-half 0] while the fragments of k-half 1 come in
                 const unsigned wsb1 = w_addr(stoff, 1), xsb1 = x_addr(bufc, sh, 1);
                 // (the last K-step runs the same instruction stream with its barrier, look-ahead reads and DMA switched off: a
                 //  separate tail would meet this path in 112 accumulator phis)
-                const bool laststep = tap == 8 && lastslab;
+                const bool laststep = tap == NTAPS - 1 && lastslab;
                 // One instruction stream for both kinds of wave: a LATE wave takes the step's barrier behind MFMA H1, the others
                 // behind the whole group.  In front of it: this wave's reads of step s are back, its pieces of stage s + 1 (and any
                 // patch piece) have landed; behind it that holds for every wave, and ring slot `stoff` / the previous slab's patch
@@ -258,10 +280,10 @@ __global__ __launch_bounds__(512, 2) void conv133g_kernel(const C133GArgs a) {
                 mma_group(IC<0>{}, IC<H1>{}, IC<H1>{}, a0, b0, a1, b1, wsb1, xsb1);
                 // What must have landed: stage s + 1.  Two slots: it is the only stage in flight (vmcnt 0).  Three slots: stage s + 2
                 // was issued behind it in the previous step - a patch piece first, then RW weight pieces - and stays in flight
-                // (vmcnt RW), unless that step was past the end of the refills (the last slab's taps 7 and 8 wait for everything).
+                // (vmcnt RW), unless that step was past the end of the refills (the last slab's last NSLOT - 1 taps wait for everything).
                 auto wait_stage = [&]() {
                     if (AF_DBG(1)) return;
-                    if (NSLOT == 2 || (tap >= 7 && lastslab)) wait_vmcnt<0>();
+                    if (NSLOT == 2 || (tap - 1 + NSLOT >= NTAPS && lastslab)) wait_vmcnt<0>();
                     else wait_vmcnt<RW>();
                 };
                 if (late && !laststep) {
@@ -279,17 +301,19 @@ __global__ __launch_bounds__(512, 2) void conv133g_kernel(const C133GArgs a) {
                 // second group: MFMA(a1, b1) [stage s, k-half 1] while the fragments of stage s + 1, k-half 0 come in; then
                 // the DMA pieces of stage s + 2 (and one piece of the next slab's patch), MPG MFMAs apart
                 const int stnext = NSLOT == 2 ? (stoff ^ WSTAGE) : (stoff == (NSLOT - 1) * WSTAGE ? 0 : stoff + WSTAGE);
-                const unsigned wsb0 = w_addr(stnext, 0), xsb0 = x_addr(tap == 8 ? bufn : bufc, nsh, 0);
-                const bool refill = (tap + NSLOT < 9 || !lastslab) && !AF_DBG(4);
-                const int wsoff = (tap + NSLOT < 9 ? wsl_c : wsl_n) + t2 * tap_bytes;
-                // behind the MFMAs of the group, one each (group2_slot: piece, read, read, piece, ...): the patch piece, the RW weight
-                // pieces, the NR look-ahead reads (behind the last step: unused reads of valid LDS)
+                const unsigned wsb0 = w_addr(stnext, 0), xsb0 = x_addr(tap == NTAPS - 1 ? bufn : bufc, nsh, 0);
+                const bool refill = (tap + NSLOT < NTAPS || !lastslab) && !AF_DBG(4);
+                const int wsoff = (tap + NSLOT < NTAPS ? wsl_c : wsl_n) + t2 * tap_bytes;
+                // behind the MFMAs of the group, one each (group2_slot: piece, read, read, piece, ...): PPS pieces of the next slab's
+                // patch, the RW weight pieces, the NR look-ahead reads (behind the last step: unused reads of valid LDS)
                 static_for<NTH>([&](auto tc) {
-                    constexpr int t = tc, slot = group2_slot(t, RW + 1, NR);
+                    constexpr int t = tc, slot = group2_slot(t, RW + PPS, NR);
                     MmaAsm<DT>::run(a1[t / MT], b1[t % MT], acc[t / MT][t % MT]);
                     if constexpr (slot != kNoSlot && slot < 0) frag_read(a0, b0, wsb0, xsb0, IC<-1 - slot>{});
-                    else if constexpr (slot == 0) { if (tap < MAXP && pp && !AF_DBG(16)) issue_patch_piece(bufn, ps1, in1, tap < MAXP ? tap : 0); }
-                    else if constexpr (slot != kNoSlot) { if (refill) issue_w_piece(stoff, wsoff, slot - 1); }
+                    else if constexpr (slot != kNoSlot && slot < PPS) {
+                        constexpr int piece = tap * PPS + slot;
+                        if constexpr (piece < MAXP && tap < PSTEPS) { if (pp && !AF_DBG(16)) issue_patch_piece(bufn, ps1, in1, piece); }
+                    } else if constexpr (slot != kNoSlot) { if (refill) issue_w_piece(stoff, wsoff, slot - PPS); }
                 });
                 stoff = stnext;
                 wait_lgkmcnt<0>();                     // a0 / b0 of the next step (read under this group) are back
@@ -320,7 +344,8 @@ __global__ __launch_bounds__(512, 2) void conv133g_kernel(const C133GArgs a) {
         // ---- epilogue: BN + ReLU + the one rounding, transposed through a per-wave patch (the patches / ring are dead),
         // whole 128-byte rows out.  Padded position p = r * WP + c -> output pixel (h0 + r, c - 1); halo columns dropped.
         OT* patch = reinterpret_cast<OT*>(smem) + wave * (16 * PROW);
-        char* obase = a.out + (((long long)frame * a.H + h0) * a.W) * a.out_ld * 2 + wn * 128;
+        char* obase = TEMPORAL ? a.out + (((long long)frame * a.T) * HW + h0) * a.out_ld * 2 + wn * 128
+                               : a.out + (((long long)frame * a.H + h0) * a.W) * a.out_ld * 2 + wn * 128;
 #pragma unroll
         for (int j = 0; j < MT; ++j) {
 #pragma unroll
@@ -334,9 +359,12 @@ __global__ __launch_bounds__(512, 2) void conv133g_kernel(const C133GArgs a) {
             for (int it = 0; it < 2; ++it) {
                 const int row = it * 8 + rr;
                 const int p = (wm * MT + j) * 16 + row;
-                const int r = (int)(((float)p + 0.5f) * a.inv_wp), c = p - r * WP;
+                const int r = (int)(((float)p + 0.5f) * a.inv_wp), c = p - r * (TEMPORAL ? a.R : WP);
                 const u32x4 o = *reinterpret_cast<const u32x4*>(patch + row * PROW + cc);
-                if (r < a.R && c >= 1 && c <= a.W && h0 + r < a.H)
+                if (TEMPORAL) {                          // position p = (frame r = p / P, pixel c = p % P): all real but a ragged last chunk
+                    if (r < a.T && h0 + c < HW)
+                        __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(obase + ((long long)r * HW + c) * a.out_ld * 2 + cc * 2));
+                } else if (r < a.R && c >= 1 && c <= a.W && h0 + r < a.H)
                     __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(obase + (long long)(r * a.W + c - 1) * a.out_ld * 2 + cc * 2));
             }
             __builtin_amdgcn_wave_barrier();
@@ -436,7 +464,7 @@ __global__ __launch_bounds__(512, 2) void conv133g_kernel(const C133GArgs a) {
     }
 }
 
-template <int DT, int WN, int WM, bool FUSEC, int MT, int MAXP, int NSLOT>
+template <int DT, int WN, int WM, bool FUSEC, int MT, int MAXP, int NSLOT, bool TEMPORAL = false>
 static int launch133g_n(const C133GArgs& a, hipStream_t stream) {
     if (a.prows > 64 * MAXP) return set_error(AF_ERR_ARG, "conv133g: %d patch rows for %d pieces per wave", a.prows, MAXP);
     int lds = 2 * a.prows * 128 + NSLOT * WN * 64 * 128;
@@ -445,8 +473,8 @@ static int launch133g_n(const C133GArgs& a, hipStream_t stream) {
     const int lds_e = 8 * 16 * (64 + 8) * 2;                                   // the epilogue's per-wave patches
     if (lds < lds_e) lds = lds_e;
     if (lds > 160 * 1024) return set_error(AF_ERR_ARG, "conv133g: %d bytes of LDS needed", lds);
-    AF_SET_MAX_LDS((&conv133g_kernel<DT, WN, WM, MT, FUSEC, MAXP, NSLOT>), 160 * 1024, "conv133g");
-    hipLaunchKernelGGL((conv133g_kernel<DT, WN, WM, MT, FUSEC, MAXP, NSLOT>), dim3(a.frames * a.upf), dim3(512), lds, stream, a);
+    AF_SET_MAX_LDS((&conv133g_kernel<DT, WN, WM, MT, FUSEC, MAXP, NSLOT, TEMPORAL>), 160 * 1024, "conv133g");
+    hipLaunchKernelGGL((conv133g_kernel<DT, WN, WM, MT, FUSEC, MAXP, NSLOT, TEMPORAL>), dim3(a.frames * a.upf), dim3(512), lds, stream, a);
     AF_CHECK_LAUNCH("conv133g_kernel");
     return AF_OK;
 }
@@ -505,6 +533,60 @@ static void fill133g(C133GArgs& a, const af_conv_desc* d, const void* in, const 
     const char* ed = getenv("AF_G_DBG");
     a.dbg = ed ? atoi(ed) : 0;
 #endif
+}
+
+// ---- TEMPORAL mode: 3x1x1 / stride 1 / pad (1,0,0) convs into 128 / 256 channels (the `a` convs of s3 / s4) on the same kernel.
+// P = pixels per unit so that T x P is the kernel's position count (224 for 256 channels, 448 for 128); 0: not this path.
+static int conv311g_pixels(const af_conv_desc* d) {
+    if (d->dtype == AF_F32 || d->tpool) return 0;
+    if (d->kt != 3 || d->kh != 1 || d->kw != 1 || d->st != 1 || d->sh != 1 || d->sw != 1) return 0;
+    if (d->pt != 1 || d->ph != 0 || d->pw != 0) return 0;
+    if (d->cin % 64 != 0 || (d->cout != 128 && d->cout != 256)) return 0;
+    const int mpad = d->cout == 256 ? 224 : 448;
+    if (d->t < 4 || mpad % d->t != 0) return 0;
+    const int P = mpad / d->t;
+    const int prows = ((d->t + 2) * P + 7) & ~7;
+    if (P < 7 || prows > 576 || 2 * prows * 128 + 2 * d->cout * 128 > 160 * 1024) return 0;
+    const long long hw = (long long)d->h * d->w, chunks = (hw + P - 1) / P, units = (long long)d->n * chunks;
+    if (units < 192 || units > 0x7fffffffLL) return 0;
+    if ((double)hw / ((double)chunks * P) < 0.6) return 0;                       // most positions of a unit are real
+    if ((long long)(d->t + 2) * hw * d->cin * 2 >= (1LL << 31)) return 0;          // 32-bit offsets inside a clip (+ the halo frames)
+    return P;
+}
+
+bool conv311g_applies(const af_conv_desc* d, const void* residual, int out_ld) {
+    static const int enabled = [] { const char* e = getenv("AF_T311G"); return e ? atoi(e) : 1; }();
+    return enabled && !residual && (out_ld == 0 || out_ld % 8 == 0) && conv311g_pixels(d) != 0;
+}
+
+int conv311g_run(const af_conv_desc* d, const void* in, const void* w_packed, const float* scale, const float* shift,
+                 void* out, int out_ld, hipStream_t stream) {
+    C133GArgs a;
+    a.in = (const char*)in; a.w = (const char*)w_packed; a.scale = scale; a.shift = shift;
+    a.H = d->h; a.W = d->w; a.Cin = d->cin; a.Cout = d->cout; a.frames = d->n;   // a "frame" of the unit decomposition is a clip
+    a.T = d->t; a.kt = 1;                                                         // (the temporal taps are the kernel's taps)
+    a.R = conv311g_pixels(d); a.upf = (d->h * d->w + a.R - 1) / a.R; a.WP = a.R;
+    a.prows = ((d->t + 2) * a.R + 7) & ~7;
+    a.kslabs = d->cin / 64; a.relu = d->relu;
+    a.inv_wp = 1.0f / (float)a.R;
+    a.w2 = nullptr; a.scale2 = a.shift2 = nullptr; a.res = nullptr; a.Cout2 = 0; a.relu2 = 0;
+    const char* es = getenv("AF_G_STAGGER");
+    a.stagger = es ? atoi(es) : 1;
+#ifdef AF_STAMPS
+    const char* ep = getenv("AF_STAMP_PTR");
+    a.stamps = ep ? (unsigned long long*)strtoull(ep, nullptr, 0) : nullptr;
+    const char* ed = getenv("AF_G_DBG");
+    a.dbg = ed ? atoi(ed) : 0;
+#endif
+    a.out = (char*)out; a.out_ld = out_ld ? out_ld : d->cout;
+    const bool three = 2 * a.prows * 128 + 3 * d->cout * 128 <= 160 * 1024;     // 256 channels, P = 14: 2 x 32 KB + 3 x 32 KB = all of LDS
+    if (d->cout == 256) {
+        if (a.prows > 64 * 5) return set_error(AF_ERR_ARG, "conv311g: %d patch rows", a.prows);
+        if (three) return d->dtype == AF_BF16 ? launch133g_n<AF_BF16, 4, 2, false, 7, 5, 3, true>(a, stream) : launch133g_n<AF_F16, 4, 2, false, 7, 5, 3, true>(a, stream);
+        return d->dtype == AF_BF16 ? launch133g_n<AF_BF16, 4, 2, false, 7, 5, 2, true>(a, stream) : launch133g_n<AF_F16, 4, 2, false, 7, 5, 2, true>(a, stream);
+    }
+    if (three) return d->dtype == AF_BF16 ? launch133g_n<AF_BF16, 2, 4, false, 7, 9, 3, true>(a, stream) : launch133g_n<AF_F16, 2, 4, false, 7, 9, 3, true>(a, stream);
+    return d->dtype == AF_BF16 ? launch133g_n<AF_BF16, 2, 4, false, 7, 9, 2, true>(a, stream) : launch133g_n<AF_F16, 2, 4, false, 7, 9, 2, true>(a, stream);
 }
 
 // b (1x3x3) + c (1x1x1, + residual, + ReLU) of a bottleneck as one launch: true iff `db` takes the frame-resident path and

@@ -248,6 +248,13 @@ CONV_CASES = [
     ("halo333_64to64_50x53_norelu", 64, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 36, 50, 53), False, False),
     ("halo333_64to128_28x28", 64, 128, (3, 3, 3), (1, 1, 1), (1, 1, 1), (2, 48, 28, 28), True, False),
     ("halo333_128to256_14x14", 128, 256, (3, 3, 3), (1, 1, 1), (1, 1, 1), (2, 100, 14, 14), True, False),
+    # round 4: the same patch-resident kernel in its TEMPORAL mode (3x1x1 into 128 / 256 channels, >= 192 units of (clip, P pixels,
+    # all T frames)): 256 channels at T = 16 (P = 14, three ring slots), a ragged last chunk, 128 channels at T = 16 (P = 28) and
+    # at T = 32 (P = 14), no ReLU
+    ("t311g_128to256_T16", 128, 256, (3, 1, 1), (1, 1, 1), (1, 0, 0), (2, 16, 28, 49), True, False),
+    ("t311g_192to256_T16_ragged", 192, 256, (3, 1, 1), (1, 1, 1), (1, 0, 0), (1, 16, 53, 51), True, False),
+    ("t311g_64to128_T16_ragged", 64, 128, (3, 1, 1), (1, 1, 1), (1, 0, 0), (1, 16, 74, 73), True, False),
+    ("t311g_128to128_T32_norelu", 128, 128, (3, 1, 1), (1, 1, 1), (1, 0, 0), (1, 32, 52, 52), False, False),
 ]
 EXPECT_VARIANT = {"c64_1x3x3_56x56": {"f16": 4, "bf16": 4}, "c64_1x3x3_30x27": {"f16": 4, "bf16": 4}, "1x3x3": {"f16": 3, "bf16": 3},
                   "tile256_1x3x3_res": 6, "tile256_ragged_m": 6, "tile224_1x3x3_res": 12, "tile224_ragged_m": 12,
@@ -263,7 +270,9 @@ EXPECT_VARIANT = {"c64_1x3x3_56x56": {"f16": 4, "bf16": 4}, "c64_1x3x3_30x27": {
                   "halo133_128to128_28x28": {"f32": 7, "f16": 11, "bf16": 11},
                   "halo133_256to128_27x26_norelu": {"f32": 7, "f16": 11, "bf16": 11},
                   "halo333_64to64_56x56": {"f16": 11, "bf16": 11}, "halo333_64to64_50x53_norelu": {"f16": 11, "bf16": 11},
-                  "halo333_64to128_28x28": {"f16": 11, "bf16": 11}, "halo333_128to256_14x14": {"f16": 11, "bf16": 11}}
+                  "halo333_64to128_28x28": {"f16": 11, "bf16": 11}, "halo333_128to256_14x14": {"f16": 11, "bf16": 11},
+                  "t311g_128to256_T16": {"f16": 13, "bf16": 13}, "t311g_192to256_T16_ragged": {"f16": 13, "bf16": 13},
+                  "t311g_64to128_T16_ragged": {"f16": 13, "bf16": 13}, "t311g_128to128_T32_norelu": {"f16": 13, "bf16": 13}}
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
