@@ -76,6 +76,12 @@ __device__ __forceinline__ float min_nan(float m, float x) { return __builtin_el
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n in [0, MAXN] (the immediate is a compile-time constant: a scalar branch chain)
+template <int MAXN, int K = 0> __device__ __forceinline__ void wait_vmcnt_dyn(int n) {
+    if constexpr (K >= MAXN) wait_vmcnt<MAXN>();
+    else { if (n == K) wait_vmcnt<K>(); else wait_vmcnt_dyn<MAXN, K + 1>(n); }
+}
+
 // LDS fragment reads hipcc does NOT count (round 4).  A software-pipelined K loop reads the fragments of half-step h + 1 while
 // half-step h multiplies; when the reads of h were issued in the previous loop iteration and the body has control flow in it
 // (conditional DMA issue), hipcc's wait insertion gives up counting across the back edge and puts s_waitcnt lgkmcnt(0) in front
@@ -86,6 +92,11 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 template <int OFF> __device__ __forceinline__ u32x4 lds_read16_uncounted(unsigned addr) {
     u32x4 r;
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF) : "memory");
+    return r;
+}
+template <int OFF> __device__ __forceinline__ unsigned lds_read4_uncounted(unsigned addr) {
+    unsigned r;
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF) : "memory");
     return r;
 }
 template <int N> __device__ __forceinline__ void wait_lgkmcnt() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }

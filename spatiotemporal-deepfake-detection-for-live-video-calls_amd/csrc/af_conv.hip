@@ -741,6 +741,15 @@ static const char* const kVariantNames[] = {"conv_igemm<BN=128,BM=256>", "conv_i
                                             "conv311g<clip-resident (T + 2) x P patch, 3 taps share it>"};
 
 static int pick_variant(int cout, int cin, int taps, int dtype, long long M, int cin2 = 0, int pooled = 0) {
+    // AF_FORCE_VAR=<variant id>: tile sweeps of tools/exp_variants.py (experiments only; a tile whose channel count does not
+    // divide the layer's is refused)
+    if (const char* fv = getenv("AF_FORCE_VAR")) {
+        const int v = atoi(fv);
+        const int bn = (v == VAR_256x256 || v == VAR_256x224) ? 256 : (v == VAR_128x256 || v == VAR_128x512 || v == VAR_128x128 || v == VAR_128x128_R2) ? 128 : 64;
+        const bool generic = v == VAR_128x256 || v == VAR_64x256 || v == VAR_128x128 || v == VAR_64x128 || v == VAR_128x128_R2 ||
+                             v == VAR_256x256 || v == VAR_128x512 || v == VAR_256x224;
+        if (generic && cout % bn == 0 && !(pooled && v == VAR_256x224)) return v;
+    }
     const int ksteps = (taps * cin + cin2) / (dtype == AF_F32 ? 32 : 64);
     const bool wide = cout % 128 == 0, short_k = ksteps <= 3;
     // (with the 2x2 pool fused only a quarter of the output is written: such a layer is MFMA-bound from 4 K-steps on)

@@ -101,9 +101,13 @@ __global__ __launch_bounds__(512, 2) void conv133g_kernel(const C133GArgs a) {
     const int pbytes = a.prows * 128;
     const unsigned ring0 = lds0 + 2 * pbytes;
 
-    // ---- work unit: (frame, band of R output rows); TEMPORAL: (clip = `frame`, chunk of R = P pixels starting at pixel h0)
-    const int unit = blockIdx.x;
-    const int frame = unit / a.upf, h0 = (unit - frame * a.upf) * a.R;
+    // ---- work units: (frame, band of R output rows); TEMPORAL: (clip = `frame`, chunk of R = P pixels starting at pixel h0).
+    // Round 4: the workgroup is PERSISTENT - unit blockIdx.x, + gridDim.x, ... - and the next unit's first operands (the first NSLOT
+    // weight stages, the patch of slab 0) are issued behind the K loop, under this unit's epilogue: a layer of several rounds of
+    // units (s3: 2, the 56 x 56 `a` conv: 7) pays one DMA latency per workgroup instead of one per unit.
+    const int units = a.frames * a.upf;
+    int unit = blockIdx.x;
+    int frame = unit / a.upf, h0 = (unit - frame * a.upf) * a.R;
     const int HW = a.H * a.W;
     // ---- producers.  Weights: thread (lrow = tid >> 3, slot = tid & 7) fetches chunk slot ^ (lrow & 7) of weight rows
     // lrow + 64 i; the K-step's (tap, slab) offset goes in an SGPR.
@@ -115,24 +119,37 @@ __global__ __launch_bounds__(512, 2) void conv133g_kernel(const C133GArgs a) {
     // Patch: LDS row j <-> padded pixel q = j - 1 = (r, c) = (q / WP, q % WP) <-> input pixel (h0 - 1 + r, c - 1); rows
     // beyond the band, halo columns and rows outside the image are out-of-range lanes (zeros).  Piece g = rows 8g .. 8g+7.
     const int NP = a.prows >> 3;
-    const int drow = lane >> 3, pchunk = (lane & 7) ^ drow;
     // K slab ks = (dt, channel slab cs): its patch comes from frame t + dt - kt / 2 of the clip; the descriptor starts kt / 2
     // frames early, dt advances by whole frames in the SGPR offset
-    const int pt = a.kt >> 1, tclip = frame % a.T;
+    const int pt = a.kt >> 1;
+    int tclip = frame % a.T;
     const int frame_bytes = a.H * a.W * a.Cin * 2;                     // < 2^29 (host-checked)
-    const i32x4 xdesc = make_desc(TEMPORAL ? a.in + ((((long long)frame * a.T - 1) * HW + h0) * a.Cin) * 2
-                                           : a.in + ((((long long)frame - pt) * a.H + h0 - 1) * a.W) * a.Cin * 2);
-    unsigned poff[MAXP];                               // (filled in behind the first weight DMAs, below)
+    auto unit_desc = [&]() {
+        return make_desc(TEMPORAL ? a.in + ((((long long)frame * a.T - 1) * HW + h0) * a.Cin) * 2
+                                  : a.in + ((((long long)frame - pt) * a.H + h0 - 1) * a.W) * a.Cin * 2);
+    };
+    i32x4 xdesc = unit_desc();
+    // The per-lane source offsets of the patch pieces (row of the patch -> input element, or out of range).  256 channels: MAXP <= 5
+    // registers; 64 channels: 9, next to 64 accumulator registers only.  128 channels (MAXP 8 - 9): a table in LDS, one word per patch row ([prows], behind the ring), read a step
+    // ahead of its use - nine cold registers next to 200 of accumulators and fragments were what hipcc spilled, and a scratch
+    // reload's vmcnt(0) inside the K loop drains the DMA.
+    constexpr bool POFF_LDS = WN == 2;
+    unsigned poff[POFF_LDS ? 1 : MAXP];
+    const unsigned tab0 = ring0 + NSLOT * WSTAGE;                        // the offset table (POFF_LDS)
+    const unsigned tabl = tab0 + (unsigned)((wave * 8 + (lane >> 3)) * 4);   // this lane's word of piece 0; piece i: + 256 i bytes
+    const unsigned pchunk16 = (unsigned)(((lane & 7) ^ (lane >> 3)) * 16);
     // patch piece i of this wave (rows 8 (wave + 8 i) ..) of K slab (frame offset + channel slab = `soff`) into patch buffer at `bufoff`
     auto patch_slab_offset = [&](int ks, bool& inclip) {
         const int dt = (ks >= a.kslabs) + (ks >= 2 * a.kslabs), cs = ks - dt * a.kslabs;
         inclip = (unsigned)(tclip + dt - pt) < (unsigned)a.T;
         return __builtin_amdgcn_readfirstlane(dt * frame_bytes + cs * 128);
     };
-    auto issue_patch_piece = [&](int bufoff, int soff, bool inclip, int i) {
+    // (voff: the piece's per-lane offset - poff[i], or the table word of the lane's row + its 16-byte chunk)
+    auto issue_patch_piece = [&](int bufoff, int soff, bool inclip, int i, unsigned voff) {
         if (wave + 8 * i < NP)
-            blds16_m0(inclip ? poff[i] : kOutOfRange, xdesc, soff, __builtin_amdgcn_readfirstlane(lds0 + bufoff + (wave + 8 * i) * 1024));
+            blds16_m0(inclip ? voff : kOutOfRange, xdesc, soff, __builtin_amdgcn_readfirstlane(lds0 + bufoff + (wave + 8 * i) * 1024));
     };
+    auto table_offset = [&](unsigned word) { return word == kOutOfRange ? kOutOfRange : word + pchunk16; };
     // weight stage of K-step (tap, slab ks) into the ring slot at byte offset `stoff`, one piece (64 rows) at a time; packed
     // [Cout][kt * 9][Cin]: offset inside a weight row = w_slab_offset(ks) + tap * Cin * 2
     auto w_slab_offset = [&](int ks) {
@@ -145,46 +162,65 @@ __global__ __launch_bounds__(512, 2) void conv133g_kernel(const C133GArgs a) {
     };
 
     f32x4 acc[NT][MT];
-#pragma unroll
-    for (int i = 0; i < NT; ++i)
-#pragma unroll
-        for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nslabs = a.kt * a.kslabs;                // K slabs (dt, cs)
     AF_STAMP_DECL;
     AF_STAMP(0); AF_STAMP(6);
-    // ---- prologue: the first NSLOT weight stages (taps 0 .. NSLOT - 1 of slab 0) are issued before the per-lane patch offsets
-    // are even computed (~100 vector instructions), then the patch of slab 0; slab 1's patch rides on the K-steps of slab 0, one
-    // piece per step, like every later one
-    {
+    // ---- a unit's first operands: the first NSLOT weight stages (taps 0 .. NSLOT - 1 of slab 0) are issued before the per-lane
+    // patch offsets are even computed (~100 vector instructions), then the patch of slab 0 into the buffer at `bufoff`; slab 1's
+    // patch rides on the K-steps of slab 0 like every later one
+    // source offset of patch row j (without the lane's chunk), or kOutOfRange
+    auto row_offset = [&](int j) -> unsigned {
+        if (TEMPORAL) {
+            // LDS row j = (frame tf = j / P of the padded clip, pixel q = j % P) <-> input (n, tf - 1, h0 + q); the descriptor
+            // starts one frame early
+            const int tf = (int)(((float)j + 0.5f) * a.inv_wp), q = j - tf * a.R;
+            const bool ok = tf >= 1 && tf <= a.T && h0 + q < HW;
+            return ok ? (unsigned)((((long long)tf * HW + q) * a.Cin) * 2) : kOutOfRange;
+        }
+        const int q = j - 1;
+        const int r = (int)(((float)q + 0.5f) * a.inv_wp), c = q - r * WP;
+        const bool ok = q >= 0 && r < a.R + 2 && c >= 1 && c <= a.W && (unsigned)(h0 - 1 + r) < (unsigned)a.H;
+        return ok ? (unsigned)(((r * a.W + (c - 1)) * a.Cin) * 2) : kOutOfRange;
+    };
+    auto compute_poff = [&]() {
+        // (from an opaque copy of the thread / lane id: hipcc otherwise computes the unit-independent half of these offsets once,
+        //  in front of the unit loop, and spills it - a scratch reload's vmcnt(0) in the prefetch block would drain the DMA around it)
+        if constexpr (POFF_LDS) {
+            int t = tid;
+            asm volatile("" : "+v"(t));
+            unsigned* tab = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(smem) + (tab0 - lds0));
+            for (int j = t; j < a.prows; j += 512) tab[j] = row_offset(j);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();              // the table is complete for every wave
+        } else {
+            int drow = lane >> 3;
+            asm volatile("" : "+v"(drow));
+#pragma unroll
+            for (int i = 0; i < MAXP; ++i) poff[i] = table_offset(row_offset((wave + 8 * i) * 8 + drow));
+        }
+    };
+    auto issue_unit_head = [&](int bufoff) {
 #pragma unroll
         for (int k = 0; k < NSLOT; ++k)
 #pragma unroll
             for (int i = 0; i < RW; ++i) issue_w_piece(k * WSTAGE, w_slab_offset(0) + k * tap_bytes, i);
-    }
-
-#pragma unroll
-    for (int i = 0; i < MAXP; ++i) {
-        if (TEMPORAL) {
-            // LDS row j = (frame tf = j / P of the padded clip, pixel q = j % P) <-> input (n, tf - 1, h0 + q); the descriptor
-            // starts one frame early
-            const int j = (wave + 8 * i) * 8 + drow;
-            const int tf = (int)(((float)j + 0.5f) * a.inv_wp), q = j - tf * a.R;
-            const bool ok = tf >= 1 && tf <= a.T && h0 + q < HW;
-            poff[i] = ok ? (unsigned)((((long long)tf * HW + q) * a.Cin) * 2 + pchunk * 16) : kOutOfRange;
-        } else {
-            const int q = (wave + 8 * i) * 8 + drow - 1;
-            const int r = (int)(((float)q + 0.5f) * a.inv_wp), c = q - r * WP;
-            const bool ok = q >= 0 && r < a.R + 2 && c >= 1 && c <= a.W && (unsigned)(h0 - 1 + r) < (unsigned)a.H;
-            poff[i] = ok ? (unsigned)(((r * a.W + (c - 1)) * a.Cin) * 2 + pchunk * 16) : kOutOfRange;
-        }
-    }
-    {
+        compute_poff();
         bool in0;
         const int ps0 = patch_slab_offset(0, in0);
+        if constexpr (POFF_LDS) {
+            unsigned w[MAXP];
+            static_for<MAXP>([&](auto i) { w[i] = lds_read4_uncounted<i * 256>(tabl); });
+            wait_lgkmcnt<0>();
 #pragma unroll
-        for (int i = 0; i < MAXP; ++i) issue_patch_piece(0, ps0, in0, i);
-    }
+            for (int i = 0; i < MAXP; ++i) { asm volatile("" : "+v"(w[i])); issue_patch_piece(bufoff, ps0, in0, i, table_offset(w[i])); }
+        } else {
+#pragma unroll
+            for (int i = 0; i < MAXP; ++i) issue_patch_piece(bufoff, ps0, in0, i, poff[i]);
+        }
+    };
+    issue_unit_head(0);
+    int bstart = 0;                                    // patch buffer of the unit's slab 0 (every later unit: the second buffer)
     const unsigned arow = ring0 + (wn * 64 + frow) * 128, brow = lds0 + (wm * MT * 16 + frow) * 128;
     // ---- the K loop: every instruction of it is an asm statement (MFMAs in place, uncounted LDS reads, LDS-DMA, waits), issued
     // in program order; hipcc allocates the registers and does the address arithmetic.
@@ -231,21 +267,26 @@ __global__ __launch_bounds__(512, 2) void conv133g_kernel(const C133GArgs a) {
         });
     };
 
-    wait_vmcnt<0>();                                   // (the weight stages went first: they are in long before the patch)
-    __builtin_amdgcn_s_barrier();
     const bool late = a.stagger && wave >= 4;
+    constexpr bool PERSIST = !FUSEC;
+    int epi_frame = 0, epi_h0 = 0;
+    bool epi_more = false;
+#pragma nounroll
+    for (;;) {
+    wait_vmcnt<0>();                                   // this unit's first operands (and the previous unit's output stores) are through
+    __builtin_amdgcn_s_barrier();                      // ... for every wave; nobody is in the previous unit's epilogue patch any more
 #pragma unroll
     for (int i = 0; i < NT; ++i)
 #pragma unroll
-        for (int j = 0; j < MT; ++j) acc_live(acc[i][j]);
+        for (int j = 0; j < MT; ++j) { acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; acc_live(acc[i][j]); }
     mfma_operands_settled();
     {
         constexpr int H1 = 3 * NTH / 4;                                    // MFMAs of a LATE wave's first group in front of its barrier
         static_assert(NR + RW + PPS <= NTH, "a DMA piece or a read per MFMA of the second group");
         int stoff = 0;                                                     // ring slot of the current step (bytes): (s % NSLOT) * WSTAGE
-        int bufc = 0, bufn = pbytes;                                       // patch buffers of this slab / the next one
+        int bufc = bstart, bufn = pbytes - bstart;                         // patch buffers of this slab / the next one
         {
-            const unsigned wsb = w_addr(0, 0), xsb = x_addr(0, 0, 0);
+            const unsigned wsb = w_addr(0, 0), xsb = x_addr(bufc, 0, 0);
             static_for<NR>([&](auto r) { frag_read(a0, b0, wsb, xsb, r); });
         }
         // (no LDS read stays pending across a tap body's end, and the slab loop is neither unrolled nor peeled: af_conv.hip's K loop
@@ -270,6 +311,14 @@ __global__ __launch_bounds__(512, 2) void conv133g_kernel(const C133GArgs a) {
                 asm volatile("" : "+s"(sh), "+s"(nsh));
                 // first group: MFMA(a0, b0) [stage s, k-half 0] while the fragments of k-half 1 come in
                 const unsigned wsb1 = w_addr(stoff, 1), xsb1 = x_addr(bufc, sh, 1);
+                // (table words of the patch pieces this step carries: read here, waited for with the group's fragment reads)
+                unsigned pw[PPS];
+                if constexpr (POFF_LDS && tap < PSTEPS) {
+                    static_for<PPS>([&](auto sl) {
+                        constexpr int piece = tap * PPS + decltype(sl)::value;
+                        if constexpr (piece < MAXP) pw[sl] = lds_read4_uncounted<piece * 256>(tabl);
+                    });
+                }
                 // (the last K-step runs the same instruction stream with its barrier, look-ahead reads and DMA switched off: a
                 //  separate tail would meet this path in 112 accumulator phis)
                 const bool laststep = tap == NTAPS - 1 && lastslab;
@@ -312,7 +361,12 @@ __global__ __launch_bounds__(512, 2) void conv133g_kernel(const C133GArgs a) {
                     if constexpr (slot != kNoSlot && slot < 0) frag_read(a0, b0, wsb0, xsb0, IC<-1 - slot>{});
                     else if constexpr (slot != kNoSlot && slot < PPS) {
                         constexpr int piece = tap * PPS + slot;
-                        if constexpr (piece < MAXP && tap < PSTEPS) { if (pp && !AF_DBG(16)) issue_patch_piece(bufn, ps1, in1, piece); }
+                        if constexpr (piece < MAXP && tap < PSTEPS) {
+                            if (pp && !AF_DBG(16)) {
+                                if constexpr (POFF_LDS) { asm volatile("" : "+v"(pw[slot])); issue_patch_piece(bufn, ps1, in1, piece, table_offset(pw[slot])); }
+                                else issue_patch_piece(bufn, ps1, in1, piece, poff[piece]);
+                            }
+                        }
                     } else if constexpr (slot != kNoSlot) { if (refill) issue_w_piece(stoff, wsoff, slot - PPS); }
                 });
                 stoff = stnext;
@@ -328,24 +382,53 @@ __global__ __launch_bounds__(512, 2) void conv133g_kernel(const C133GArgs a) {
 
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                      // every wave is done with the patches and the ring
+    if constexpr (FUSEC) break;
     // (the epilogue's lane-derived values start from an opaque copy of the lane id: nothing of its address arithmetic can be
     //  computed - and kept in registers - across the K loop)
     int lane_e = lane;
     asm volatile("" : "+v"(lane_e));
     const int frow_e = lane_e & 15, fg_e = lane_e >> 4;
+    // BN parameters: loads hipcc does not count, issued BEFORE the next unit's DMA - its own wait for them would be vmcnt(0),
+    // i.e. for the DMA issued behind them as well - and waited for with the number of younger operations of this wave
     f32x4 sc[NT], sf[NT];
+    {
+        uint4 scr[NT], sfr[NT];
 #pragma unroll
-    for (int i = 0; i < NT; ++i) {
-        sc[i] = *reinterpret_cast<const f32x4*>(a.scale + wn * 64 + i * 16 + fg_e * 4);
-        sf[i] = *reinterpret_cast<const f32x4*>(a.shift + wn * 64 + i * 16 + fg_e * 4);
+        for (int i = 0; i < NT; ++i) {
+            scr[i] = gload16_uncounted(a.scale + wn * 64 + i * 16 + fg_e * 4);
+            sfr[i] = gload16_uncounted(a.shift + wn * 64 + i * 16 + fg_e * 4);
+        }
+        // ---- the next unit of this workgroup: geometry, then its first operands into the ring and the patch buffer the epilogue
+        // does not use (the transposition patches live at the start of buffer 0)
+        const int e_frame = frame, e_h0 = h0;
+        const int next = unit + (int)gridDim.x;
+        const bool has_next = PERSIST && next < units;
+        int younger = 0;
+        if (has_next) {
+            unit = next;
+            frame = unit / a.upf; h0 = (unit - frame * a.upf) * a.R; tclip = frame % a.T;
+            xdesc = unit_desc();
+            issue_unit_head(pbytes);
+            bstart = pbytes;
+            int np = (NP - wave + 7) >> 3;
+            younger = NSLOT * RW + (np < MAXP ? np : MAXP);
+        }
+        wait_vmcnt_dyn<NSLOT * RW + MAXP>(younger);
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            u32x4 t0 = __builtin_bit_cast(u32x4, scr[i]), t1 = __builtin_bit_cast(u32x4, sfr[i]);
+            pin_frag(t0); pin_frag(t1);
+            sc[i] = __builtin_bit_cast(f32x4, t0); sf[i] = __builtin_bit_cast(f32x4, t1);
+        }
+        epi_frame = e_frame; epi_h0 = e_h0; epi_more = has_next;
     }
     const int rr = lane_e >> 3, cc = (lane_e & 7) * 8;
     if (!FUSEC) {
         // ---- epilogue: BN + ReLU + the one rounding, transposed through a per-wave patch (the patches / ring are dead),
         // whole 128-byte rows out.  Padded position p = r * WP + c -> output pixel (h0 + r, c - 1); halo columns dropped.
         OT* patch = reinterpret_cast<OT*>(smem) + wave * (16 * PROW);
-        char* obase = TEMPORAL ? a.out + (((long long)frame * a.T) * HW + h0) * a.out_ld * 2 + wn * 128
-                               : a.out + (((long long)frame * a.H + h0) * a.W) * a.out_ld * 2 + wn * 128;
+        char* obase = TEMPORAL ? a.out + (((long long)epi_frame * a.T) * HW + epi_h0) * a.out_ld * 2 + wn * 128
+                               : a.out + (((long long)epi_frame * a.H + epi_h0) * a.W) * a.out_ld * 2 + wn * 128;
 #pragma unroll
         for (int j = 0; j < MT; ++j) {
 #pragma unroll
@@ -362,17 +445,27 @@ __global__ __launch_bounds__(512, 2) void conv133g_kernel(const C133GArgs a) {
                 const int r = (int)(((float)p + 0.5f) * a.inv_wp), c = p - r * (TEMPORAL ? a.R : WP);
                 const u32x4 o = *reinterpret_cast<const u32x4*>(patch + row * PROW + cc);
                 if (TEMPORAL) {                          // position p = (frame r = p / P, pixel c = p % P): all real but a ragged last chunk
-                    if (r < a.T && h0 + c < HW)
+                    if (r < a.T && epi_h0 + c < HW)
                         __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(obase + ((long long)r * HW + c) * a.out_ld * 2 + cc * 2));
-                } else if (r < a.R && c >= 1 && c <= a.W && h0 + r < a.H)
+                } else if (r < a.R && c >= 1 && c <= a.W && epi_h0 + r < a.H)
                     __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(obase + (long long)(r * a.W + c - 1) * a.out_ld * 2 + cc * 2));
             }
             __builtin_amdgcn_wave_barrier();
         }
+        if (epi_more) continue;
         AF_STAMP(3); AF_STAMP(7);
         AF_STAMP_FLUSH;
         return;
     }
+    }                                                  // (unit loop; the fused `c` instantiations leave it behind their one unit's K loop)
+    f32x4 sc[NT], sf[NT];
+    const int frow_e = frow, fg_e = fg;
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        sc[i] = *reinterpret_cast<const f32x4*>(a.scale + wn * 64 + i * 16 + fg_e * 4);
+        sf[i] = *reinterpret_cast<const f32x4*>(a.shift + wn * 64 + i * 16 + fg_e * 4);
+    }
+    const int rr = lane >> 3, cc = (lane & 7) * 8;
 
     // ---- fused `c` conv.  The band's b output (BN + ReLU, rounded once) becomes the B operand of a 1x1x1 convolution without
     // leaving the CU: T[slab = wn][position p][64 channels] in LDS, swizzled like the patches (halo columns hold garbage that
@@ -467,14 +560,18 @@ __global__ __launch_bounds__(512, 2) void conv133g_kernel(const C133GArgs a) {
 template <int DT, int WN, int WM, bool FUSEC, int MT, int MAXP, int NSLOT, bool TEMPORAL = false>
 static int launch133g_n(const C133GArgs& a, hipStream_t stream) {
     if (a.prows > 64 * MAXP) return set_error(AF_ERR_ARG, "conv133g: %d patch rows for %d pieces per wave", a.prows, MAXP);
-    int lds = 2 * a.prows * 128 + NSLOT * WN * 64 * 128;
+    int lds = 2 * a.prows * 128 + NSLOT * WN * 64 * 128 + (WN == 2 ? a.prows * 4 : 0);      // patches, ring, the patch-row offset table (128 channels)
     const int lds_c = WN * (WM * MT * 16) * 128 + 8 * 16 * (64 + 4) * 4;      // T + the per-wave fp32 staging rows
     if (FUSEC && lds_c > lds) lds = lds_c;
     const int lds_e = 8 * 16 * (64 + 8) * 2;                                   // the epilogue's per-wave patches
     if (lds < lds_e) lds = lds_e;
     if (lds > 160 * 1024) return set_error(AF_ERR_ARG, "conv133g: %d bytes of LDS needed", lds);
     AF_SET_MAX_LDS((&conv133g_kernel<DT, WN, WM, MT, FUSEC, MAXP, NSLOT, TEMPORAL>), 160 * 1024, "conv133g");
-    hipLaunchKernelGGL((conv133g_kernel<DT, WN, WM, MT, FUSEC, MAXP, NSLOT, TEMPORAL>), dim3(a.frames * a.upf), dim3(512), lds, stream, a);
+    // persistent workgroups (one per CU: the kernel uses all of LDS): unit blockIdx.x, + gridDim.x, ...
+    const int units = a.frames * a.upf, cus = device_cus();
+    static const int persist = [] { const char* e = getenv("AF_G_PERSIST"); return e ? atoi(e) : 1; }();   // 0: one unit per workgroup (A/B runs)
+    const int grid = (FUSEC || !persist || units <= cus || cus <= 0) ? units : cus;
+    hipLaunchKernelGGL((conv133g_kernel<DT, WN, WM, MT, FUSEC, MAXP, NSLOT, TEMPORAL>), dim3(grid), dim3(512), lds, stream, a);
     AF_CHECK_LAUNCH("conv133g_kernel");
     return AF_OK;
 }
@@ -482,7 +579,7 @@ static int launch133g_n(const C133GArgs& a, hipStream_t stream) {
 // three ring slots (two K-steps of weights in flight) where the two patch buffers leave room for them (s4: 2 x 31 KB + 3 x 32 KB)
 template <int DT, int WN, int WM, bool FUSEC, int MT = 7, int MAXP = 9>
 static int launch133g(const C133GArgs& a, hipStream_t stream) {
-    if (!FUSEC && 2 * a.prows * 128 + 3 * WN * 64 * 128 <= 160 * 1024) return launch133g_n<DT, WN, WM, FUSEC, MT, MAXP, FUSEC ? 2 : 3>(a, stream);
+    if (!FUSEC && 2 * a.prows * 128 + 3 * WN * 64 * 128 + (WN == 2 ? a.prows * 4 : 0) <= 160 * 1024) return launch133g_n<DT, WN, WM, FUSEC, MT, MAXP, FUSEC ? 2 : 3>(a, stream);
     return launch133g_n<DT, WN, WM, FUSEC, MT, MAXP, 2>(a, stream);
 }
 
@@ -498,7 +595,8 @@ static int conv133g_rows(const af_conv_desc* d) {
     int r = mpad / wp;
     if (r > d->h) r = d->h;
     auto patch_rows = [&](int rows) { return ((rows + 2) * wp + 1 + 7) & ~7; };
-    while (r >= 7 && (patch_rows(r) > 576 || 2 * patch_rows(r) * 128 + 2 * d->cout * 128 > 160 * 1024)) --r;   // two patches + the ring
+    const int tab = d->cout == 128 ? 4 : 0;                   // bytes per patch row of the offset table (128 channels)
+    while (r >= 7 && (patch_rows(r) > 576 || 2 * patch_rows(r) * 128 + 2 * d->cout * 128 + patch_rows(r) * tab > 160 * 1024)) --r;   // two patches + the ring (+ the table)
     if (r < 7) return 0;                                       // bands of >= 7 rows: the halo rows stay <= 2/7 of the patch
     int upf = (d->h + r - 1) / r;
     r = (d->h + upf - 1) / upf;                                // even bands
@@ -546,7 +644,7 @@ static int conv311g_pixels(const af_conv_desc* d) {
     if (d->t < 4 || mpad % d->t != 0) return 0;
     const int P = mpad / d->t;
     const int prows = ((d->t + 2) * P + 7) & ~7;
-    if (P < 7 || prows > 576 || 2 * prows * 128 + 2 * d->cout * 128 > 160 * 1024) return 0;
+    if (P < 7 || prows > 576 || 2 * prows * 128 + 2 * d->cout * 128 + (d->cout == 128 ? prows * 4 : 0) > 160 * 1024) return 0;
     const long long hw = (long long)d->h * d->w, chunks = (hw + P - 1) / P, units = (long long)d->n * chunks;
     if (units < 192 || units > 0x7fffffffLL) return 0;
     if ((double)hw / ((double)chunks * P) < 0.6) return 0;                       // most positions of a unit are real
@@ -579,7 +677,7 @@ int conv311g_run(const af_conv_desc* d, const void* in, const void* w_packed, co
     a.dbg = ed ? atoi(ed) : 0;
 #endif
     a.out = (char*)out; a.out_ld = out_ld ? out_ld : d->cout;
-    const bool three = 2 * a.prows * 128 + 3 * d->cout * 128 <= 160 * 1024;     // 256 channels, P = 14: 2 x 32 KB + 3 x 32 KB = all of LDS
+    const bool three = 2 * a.prows * 128 + 3 * d->cout * 128 + (d->cout == 128 ? a.prows * 4 : 0) <= 160 * 1024;     // 256 channels, P = 14: 2 x 32 KB + 3 x 32 KB = all of LDS
     if (d->cout == 256) {
         if (a.prows > 64 * 5) return set_error(AF_ERR_ARG, "conv311g: %d patch rows", a.prows);
         if (three) return d->dtype == AF_BF16 ? launch133g_n<AF_BF16, 4, 2, false, 7, 5, 3, true>(a, stream) : launch133g_n<AF_F16, 4, 2, false, 7, 5, 3, true>(a, stream);

@@ -39,20 +39,20 @@ def main():
         ("#11 s3.res0.c+br1", mk(B, 16, 28, 28, 128, 512), mk(B, 16, 56, 56, 256, 512, s=(1, 2, 2)), False, (6, 0, 5, 2)),
         ("#23 s4.res0.c+br1", mk(B, 16, 14, 14, 256, 1024), mk(B, 16, 28, 28, 512, 1024, s=(1, 2, 2)), False, (6, 0, 5, 2)),
         ("#41 s5.res0.c+br1", mk(B, 16, 7, 7, 512, 2048), mk(B, 16, 14, 14, 1024, 2048, s=(1, 2, 2)), False, (6, 0, 5, 2)),
-        ("#12 s3 a 512->128", mk(B, 16, 28, 28, 512, 128), None, False, (0, 2, 5, 1, 3)),
-        ("#24 s4 a 1024->256", mk(B, 16, 14, 14, 1024, 256), None, False, (6, 0, 5, 2)),
-        ("#39 s5.res0.a 1024->512", mk(B, 16, 14, 14, 1024, 512), None, False, (6, 0, 5, 2)),
-        ("#44 s5 c 512->2048 +res", mk(B, 16, 7, 7, 512, 2048), None, True, (2, 5, 0, 6)),
-        ("#45 s5 a 2048->512", mk(B, 16, 7, 7, 2048, 512), None, False, (0, 6, 2, 5)),
+        ("#12 s3 a 512->128", mk(B, 16, 28, 28, 512, 128), None, False, (0, 2, 5, 7)),
+        ("#24 s4 a 1024->256", mk(B, 16, 14, 14, 1024, 256), None, False, (6, 12, 0, 5, 2)),
+        ("#39 s5.res0.a 1024->512", mk(B, 16, 14, 14, 1024, 512), None, False, (6, 12, 0, 5, 2)),
+        ("#44 s5 c 512->2048 +res", mk(B, 16, 7, 7, 512, 2048), None, True, (2, 5, 0, 6, 12)),
+        ("#45 s5 a 2048->512", mk(B, 16, 7, 7, 2048, 512), None, False, (0, 6, 12, 2, 5)),
         ("#10 s3.res0.b s2", mk(B, 16, 56, 56, 128, 128, (1, 3, 3), (1, 2, 2), (0, 1, 1)), None, False, (7, 0, 2)),
-        ("#22 s4.res0.b s2", mk(B, 16, 28, 28, 256, 256, (1, 3, 3), (1, 2, 2), (0, 1, 1)), None, False, (6, 0, 2)),
-        ("#40 s5.res0.b s2", mk(B, 16, 14, 14, 512, 512, (1, 3, 3), (1, 2, 2), (0, 1, 1)), None, False, (0, 6, 2)),
-        ("#43 s5 b", mk(B, 16, 7, 7, 512, 512, (1, 3, 3), (1, 1, 1), (0, 1, 1)), None, False, (0, 6, 2)),
-        ("#42 s5 a 3x1x1", mk(B, 16, 7, 7, 2048, 512, (3, 1, 1), (1, 1, 1), (1, 0, 0)), None, False, (0, 6, 2)),
+        ("#22 s4.res0.b s2", mk(B, 16, 28, 28, 256, 256, (1, 3, 3), (1, 2, 2), (0, 1, 1)), None, False, (6, 12, 0, 2)),
+        ("#40 s5.res0.b s2", mk(B, 16, 14, 14, 512, 512, (1, 3, 3), (1, 2, 2), (0, 1, 1)), None, False, (0, 6, 12, 2)),
+        ("#43 s5 b", mk(B, 16, 7, 7, 512, 512, (1, 3, 3), (1, 1, 1), (0, 1, 1)), None, False, (0, 6, 12, 2)),
+        ("#42 s5 a 3x1x1", mk(B, 16, 7, 7, 2048, 512, (3, 1, 1), (1, 1, 1), (1, 0, 0)), None, False, (0, 6, 12, 2)),
         ("#21 s4.res0.a 3x1x1", mk(B, 16, 28, 28, 512, 256, (3, 1, 1), (1, 1, 1), (1, 0, 0)), None, False, (6, 0, 2)),
         ("#27 s4 a 3x1x1", mk(B, 16, 14, 14, 1024, 256, (3, 1, 1), (1, 1, 1), (1, 0, 0)), None, False, (6, 0, 2)),
     ]
-    names = {0: "128x256", 1: "64x256", 2: "128x128", 3: "64x128", 5: "128x128r2", 6: "256x256", 7: "128x512"}
+    names = {0: "128x256", 1: "64x256", 2: "128x128", 3: "64x128", 5: "128x128r2", 6: "256x256", 7: "128x512", 12: "256x224"}
     for name, d, d2, res, variants in CASES:
         os.environ.pop("AF_FORCE_VAR", None)
         run = layer(d, d2, res)
