@@ -108,16 +108,24 @@ __global__ __launch_bounds__(512, 1) void conv111_kernel(const C111Args a) {
             wreg[i][2 * KS1 + k] = *reinterpret_cast<const uint4*>(a.w2 + (ch * a.Cin2 + k * 32 + fg * 8) * ES);
     }
 
-    // ---- epilogue geometry: lane = (row rr of RPI, 8 channels at cc) of a 16-row patch
-    const int rr = lane / LPR, cc = (lane % LPR) * 8;
+    // ---- epilogue geometry: lane = (row rr of RPI, 8 channels at cc) of a 16-row patch.
+    // REGEPI (round 4, the 32-channel wave columns of K = 256): no patch - the packed halves of the wave's two channel tiles trade
+    // places between lane rows (v_permlane16_swap, swap_pair16), so lane (position frow, group fg) holds 8 consecutive channels:
+    // row rr = frow, channels (fg & 1) * 16 + (fg >> 1) * 8 .. + 7 - the same 64-byte row segments per wave instruction as the
+    // patch form wrote, without four LDS round trips per tile on an in-order wave; the residual rows arrive in that layout and are
+    // traded back into tile order for the fp32 sum.  Measured: a tie with the patch form (59.1 against 58.5 us for s4's c conv): the
+    // launch is bound by its 64-byte memory segments (4.6 TB/s with the compute switched off), not by the transposition.
+    constexpr bool REGEPI = WC == 32;
+    const int rr = REGEPI ? frow : lane / LPR, cc = REGEPI ? (fg & 1) * 16 + (fg >> 1) * 8 : (lane % LPR) * 8;
     const int ch0 = col * 256 + wn * WC + cc;
-    // BN scale / shift of this lane's 8 channels: registers (read from LDS per use they were a third of the kernel's LDS
-    // traffic; the two-pass accumulators left the room)
+    // BN scale / shift: of this lane's 8 channels in row order, or (REGEPI) of its 4 channels of tile 0 and of tile 1: registers
+    // (read from LDS per use they were a third of the kernel's LDS traffic; the two-pass accumulators left the room)
     f32x4 sc[2], sf[2];
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-        sc[e] = *reinterpret_cast<const f32x4*>(a.scale + ch0 + 4 * e);
-        sf[e] = *reinterpret_cast<const f32x4*>(a.shift + ch0 + 4 * e);
+        const int chp = REGEPI ? col * 256 + wn * WC + e * 16 + fg * 4 : ch0 + 4 * e;
+        sc[e] = *reinterpret_cast<const f32x4*>(a.scale + chp);
+        sf[e] = *reinterpret_cast<const f32x4*>(a.shift + chp);
     }
 
     // ---- producer: per-lane source offsets of the 2 DMA pieces (8 rows each) this wave brings in per K slab
@@ -249,6 +257,31 @@ __global__ __launch_bounds__(512, 1) void conv111_kernel(const C111Args a) {
                     for (int jl = 0; jl < 2; ++jl) Mma<DT>::run(wreg[i][k], bf[jl], acc[i][jl]);
             }
 
+            if constexpr (REGEPI) {
+                // ---- epilogue in registers: BN in tile order, + the residual traded back into tile order, ReLU, the one rounding,
+                // then the packed halves of the two tiles trade lane rows: 16 bytes = 8 consecutive channels per lane
+                const float lo = a.relu ? 0.f : -__builtin_inff();
+#pragma unroll
+                for (int jl = 0; jl < 2; ++jl) {
+                    const int j = 2 * h + jl, row = wm * WPOS + j * 16 + rr;
+                    f32x4 v0 = acc[0][jl] * sc[0] + sf[0], v1 = acc[1][jl] * sc[1] + sf[1];
+                    if (RES) {
+                        const u32x4 x = rcur[j];
+                        const u32x2 s0 = __builtin_amdgcn_permlane16_swap(x[0], x[2], false, false);
+                        const u32x2 s1 = __builtin_amdgcn_permlane16_swap(x[1], x[3], false, false);
+                        const u32x2 ra = u32x2{s0[0], s1[0]}, rb = u32x2{s0[1], s1[1]};
+                        v0 += Vec4<DT>::load(&ra); v1 += Vec4<DT>::load(&rb);
+                    }
+                    v0[0] = max_nan(v0[0], lo); v0[1] = max_nan(v0[1], lo); v0[2] = max_nan(v0[2], lo); v0[3] = max_nan(v0[3], lo);
+                    v1[0] = max_nan(v1[0], lo); v1[1] = max_nan(v1[1], lo); v1[2] = max_nan(v1[2], lo); v1[3] = max_nan(v1[3], lo);
+                    u32x2 p0, p1;
+                    Vec4<DT>::store(&p0, v0); Vec4<DT>::store(&p1, v1);
+                    const u32x4 o = swap_pair16(p0, p1);
+                    if (row_live(row, live))
+                        __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(obase + out_soff(j) + out_lane));
+                }
+                continue;
+            }
             // ---- epilogue: 16 positions at a time through the wave's patch
             float keep[ITS][8];                          // tpool: frame 0 of the pixel rows, waiting for frame 1
 #pragma unroll
@@ -360,6 +393,8 @@ int conv111_run(const af_conv_desc* d, const void* in, const void* w_packed, con
     if (d2) return AF_C111(1, 1, false, false);
     if (d->tpool) return residual ? AF_C111(1, 0, true, true) : AF_C111(1, 0, true, false);
     if (d->cin == 64) return residual ? AF_C111(1, 0, false, true) : AF_C111(1, 0, false, false);
+    // (64-channel wave columns for K = 256 - 128-byte row segments instead of 64 - were tried in round 4: 128 weight registers next to
+    //  three residual sets spill 11 registers at two waves per SIMD, and a scratch reload's vmcnt(0) is poison in this loop)
     if (d->cin == 256)     // 32-channel wave columns: the weights of 64 channels x 256 would not fit the registers
         return residual ? (bf ? launch111<AF_BF16, 4, 0, false, true, 32, 64, 4>(a, blocks, stream) : launch111<AF_F16, 4, 0, false, true, 32, 64, 4>(a, blocks, stream))
                         : (bf ? launch111<AF_BF16, 4, 0, false, false, 32, 64, 4>(a, blocks, stream) : launch111<AF_F16, 4, 0, false, false, 32, 64, 4>(a, blocks, stream));
