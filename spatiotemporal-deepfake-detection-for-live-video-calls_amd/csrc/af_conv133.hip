@@ -304,6 +304,7 @@ __global__ __launch_bounds__(512, 2) void conv133_c64x2_kernel(const C133Args a)
         // its fragment of step s - still a whole step (8 MFMAs of this wave) ahead of its use, with half the registers of two
         // sets (two sets + 144 weight registers spilled)
         uint4 bf[MT];
+        uint4 aw[2][NT2];                                            // LDS-resident weight fragments of the step / the next step (taps 7, 8)
         auto read_frag = [&](int step, int k) {
             const int tap = step >> 1, kk = step & 1;
             const int row = frow + (tap / 3) * WP + (tap % 3);
@@ -314,12 +315,19 @@ __global__ __launch_bounds__(512, 2) void conv133_c64x2_kernel(const C133Args a)
 #pragma unroll
         for (int step = 0; step < 18; ++step) {
             if (step == 6 && s > s0) store_tile(s - 1);
+            // (round 4: the LDS-resident weight fragments of the last two taps are read ONCE per step, in front of its four m-tiles;
+            //  read per use - hipcc does not merge loads across the sched_barriers - every MFMA pair of those four steps waited
+            //  for an LDS round trip of its own: `rr [lgkmcnt(1)] M` in the ISA)
+            //  ... and a whole step ahead of its use (two fragment sets, alternating by step parity)
+            if (step + 1 >= 2 * RT && step + 1 < 18) {
+#pragma unroll
+                for (int i = 0; i < NT2; ++i) aw[(step + 1) & 1][i] = w8[((((step + 1) >> 1) - RT) * 8 + ((step + 1) & 1) * 4 + ng * 2 + i) * 64 + lane];
+            }
 #pragma unroll
             for (int k = 0; k < MT; ++k) {
 #pragma unroll
                 for (int i = 0; i < NT2; ++i)
-                    Mma<DT>::run(step < 2 * RT ? __builtin_bit_cast(uint4, wreg[step < 2 * RT ? step >> 1 : 0][step & 1][i])
-                                               : w8[(((step >> 1) - RT) * 8 + (step & 1) * 4 + ng * 2 + i) * 64 + lane],
+                    Mma<DT>::run(step < 2 * RT ? __builtin_bit_cast(uint4, wreg[step < 2 * RT ? step >> 1 : 0][step & 1][i]) : aw[step & 1][i],
                                  bf[k], acc[i][k]);
                 if (step + 1 < 18) bf[k] = read_frag(step + 1, k);
                 __builtin_amdgcn_sched_barrier(0);
