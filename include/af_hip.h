@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define AF_ABI_VERSION 3
+#define AF_ABI_VERSION 4
 
 enum af_dtype { AF_F32 = 0, AF_BF16 = 1, AF_F16 = 2 };
 
@@ -361,6 +361,24 @@ typedef struct af_stage_rect {
     int32_t rows, row_bytes;
 } af_stage_rect;
 int af_stage_rows_u8(void* dst, const af_stage_rect* rects, int n);
+
+/* Host-side planning of ONE clip for the aligner (no device work; ABI 4): what FasterCropAlignXRay.__call__ does per frame between the
+ * similarity fit and the warp (reference altfreezing/test_tools/faster_crop_align_xray.py:75-88: paste every crop on the common
+ * canvas, warp), as one call instead of a Python loop per frame.  crops[i]: the HxWx3 uint8 crop (first byte, row pitch in bytes -
+ * pixels of a row contiguous - height, width) and its paste offset (x, y) on the canvas_w x canvas_h canvas; tfm: the forward 2x3
+ * matrix; size: the output edge.  Checks that every crop fits the canvas (AF_ERR_ARG with the frame in *bad_frame: numpy's slice
+ * assignment raises there in the reference), cuts each crop to the rows the size x size destination can sample (bilinear taps +
+ * fixed-point rounding: 3 pixels of margin; a crop cut to rows [r0, r1) is that shorter crop pasted r0 rows lower) and fills
+ * rects[i] (what af_stage_rows_u8 copies into the staging buffer, 16-byte aligned pieces), frames[i] (what af_warp_affine_clip_u8
+ * reads) and *total_bytes (staging bytes used). */
+typedef struct af_align_crop {
+    const void* src;
+    int64_t pitch;
+    int32_t h, w;
+    int32_t x, y;
+} af_align_crop;
+int af_align_plan_u8(const af_align_crop* crops, int n, int canvas_h, int canvas_w, const double* tfm, int size,
+                     af_stage_rect* rects, af_align_frame* frames, int64_t* total_bytes, int32_t* bad_frame);
 
 /* ---- whole-forward op list ------------------------------------------------------------ */
 

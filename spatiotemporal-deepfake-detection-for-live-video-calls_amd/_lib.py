@@ -10,7 +10,7 @@ AF_F32, AF_BF16, AF_F16 = 0, 1, 2
 (AF_OP_STEM, AF_OP_CONV, AF_OP_MAXPOOL, AF_OP_HEAD, AF_OP_PACK_F32, AF_OP_PACK_U8, AF_OP_CONV_DUAL, AF_OP_STEM_POOL, AF_OP_AVGPOOL,
  AF_OP_LINEAR, AF_OP_TSTEM, AF_OP_TOKENS, AF_OP_LAYERNORM, AF_OP_ATTENTION, AF_OP_GELU, AF_OP_CONV_BC, AF_OP_PACK3_F32,
  AF_OP_PACK3_U8, AF_OP_STEM3_POOL, AF_OP_CONV_CA, AF_OP_BLOCK_ABC, AF_OP_TSTEM_POOL3, AF_OP_CONV_CPA) = range(23)
-AF_ABI_VERSION = 3
+AF_ABI_VERSION = 4
 STEM_PAD_T, STEM_PAD_H, STEM_PAD_W_LEFT, STEM_PAD_W_TOTAL, STEM_CPAD = 2, 3, 3, 8, 4
 
 DTYPE_CODES = {"f32": AF_F32, "bf16": AF_BF16, "f16": AF_F16}
@@ -28,6 +28,10 @@ class StageRect(C.Structure):
 
 class AlignFrame(C.Structure):
     _fields_ = [("offset", C.c_int64), ("ih", C.c_int32), ("iw", C.c_int32), ("x", C.c_int32), ("y", C.c_int32)]
+
+
+class AlignCrop(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("pitch", C.c_int64), ("h", C.c_int32), ("w", C.c_int32), ("x", C.c_int32), ("y", C.c_int32)]
 
 
 ALIGN_MAX_FRAMES = 64
@@ -92,6 +96,7 @@ ABI = {
                               + [C.c_int, C.c_void_p]),
     "af_conv_ca_fusable": (C.c_int, [C.POINTER(ConvDesc)] * 3),
     "af_stage_rows_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "af_align_plan_u8": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "af_conv_cpa_fusable": (C.c_int, [C.POINTER(ConvDesc)] * 2 + [C.c_int]),
     "af_conv3d_cpa_bn_act": (C.c_int, [C.POINTER(ConvDesc)] + [C.c_void_p] * 6 + [C.c_int, C.POINTER(ConvDesc)] + [C.c_void_p] * 5),
     "af_conv3d_ca_bn_act": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_void_p, C.POINTER(ConvDesc)] + [C.c_void_p] * 6

@@ -163,6 +163,8 @@ class FasterCropAlignXRay:
         out = torch.empty((len(images), self.image_size, self.image_size, 3), dtype=torch.uint8, device=dev)
         if len(images) == 0:
             return out
+        if not _CLIP_COLUMNS:
+            return self._warp_clip_planned(images, diff, h, w, tfm, out, dev)
         # only the part of a crop the warp can touch is uploaded: the destination square maps to a parallelogram of the canvas;
         # a crop cut to rows [r0, r1) x columns [c0, c1) is the same picture as that smaller crop pasted (c0, r0) further in
         # (everything else it would have covered is never sampled), so the kernel's frame table takes the moved origin and the
@@ -183,6 +185,62 @@ class FasterCropAlignXRay:
             ev = torch.cuda.Event()
             ev.record()
             self._ring.done[slot] = ev
+        return out
+
+    def _warp_clip_planned(self, images, diff, h: int, w: int, tfm, out: torch.Tensor, dev) -> torch.Tensor:
+        """warp_clip with the per-frame work in C (round 4): ONE Python pass over the crops collects (address, pitch, shape, paste
+        offset); af_align_plan_u8 checks the canvas fit, cuts every crop to the rows the warp can sample and fills the staging
+        table and the kernel's frame table; then the staging copy (two threads), one H2D copy, one warp launch per <= 64 frames.
+        Same arithmetic as the Python path it replaces (_clip_rect + stage_crops_ring + launch_warps, still used by the column-cut
+        experiment and the streaming aligner): the clip is bit for bit the same."""
+        from . import _lib
+        n = len(images)
+        crops = (_lib.AlignCrop * n)()
+        keep = []                                      # every array whose address goes into `crops` lives until the copies return
+        for i, im in enumerate(images):
+            if not (isinstance(im, np.ndarray) and im.dtype == np.uint8 and im.ndim == 3 and im.shape[2] == 3):
+                raise AssertionError("aligner: images must be HxWx3 uint8 numpy arrays")
+            st = im.strides
+            if st[2] != 1 or st[1] != 3 or st[0] < im.shape[1] * 3:
+                im = np.ascontiguousarray(im)
+                st = im.strides
+            keep.append(im)
+            crops[i] = _lib.AlignCrop(im.__array_interface__["data"][0], st[0], im.shape[0], im.shape[1], int(diff[i][0]), int(diff[i][1]))
+        rects = (_lib.StageRect * n)()
+        frames = (_lib.AlignFrame * n)()
+        total, bad = C.c_int64(0), C.c_int32(-1)
+        m = (C.c_double * 6)(*np.asarray(tfm, dtype=np.float64).reshape(6).tolist())
+        rc = _lib.lib.af_align_plan_u8(crops, n, int(h), int(w), m, self.image_size, rects, frames, C.byref(total), C.byref(bad))
+        if rc != 0 and bad.value >= 0:
+            i, im = bad.value, keep[bad.value]
+            # numpy refuses new_image[y:y+ih, x:x+iw] = image for a crop that sticks out of the canvas
+            raise ValueError("aligner: frame %d (%dx%d at %d,%d) does not fit the %dx%d canvas"
+                             % (i, im.shape[1], im.shape[0], int(diff[i][0]), int(diff[i][1]), w, h))
+        _lib.check(rc, "align_plan_u8")
+        with torch.cuda.device(dev):
+            k = self._ring.acquire(total.value, dev)
+            base = self._ring.host[k].data_ptr()
+            nt = min(_COPY_THREADS, n)
+            if nt > 1 and total.value >= (1 << 20):
+                cuts = [n * t // nt for t in range(nt + 1)]
+                def part(t):
+                    _lib.check(_lib.lib.af_stage_rows_u8(C.c_void_p(base), C.byref(rects, cuts[t] * C.sizeof(_lib.StageRect)), cuts[t + 1] - cuts[t]),
+                               "stage_rows_u8")
+                list(_pool().map(part, range(nt)))
+            else:
+                _lib.check(_lib.lib.af_stage_rows_u8(C.c_void_p(base), rects, n), "stage_rows_u8")
+            del keep
+            d = self._ring.dev[k]
+            d[:total.value].copy_(self._ring.host[k][:total.value], non_blocking=True)
+            stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            for lo in range(0, n, _lib.ALIGN_MAX_FRAMES):
+                hi = min(n, lo + _lib.ALIGN_MAX_FRAMES)
+                _lib.check(_lib.lib.af_warp_affine_clip_u8(C.c_void_p(d.data_ptr()), C.byref(frames, lo * C.sizeof(_lib.AlignFrame)), hi - lo,
+                                                           int(h), int(w), m, self.image_size, C.c_void_p(out[lo:hi].data_ptr()), stream),
+                           "warp_affine_clip_u8")
+            ev = torch.cuda.Event()
+            ev.record()
+            self._ring.done[k] = ev
         return out
 
     def _clip_rect(self, images: Sequence[np.ndarray], diff: np.ndarray, tfm: np.ndarray):

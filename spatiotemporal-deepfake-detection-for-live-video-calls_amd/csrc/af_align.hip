@@ -12,6 +12,7 @@
 // from the build image and the reference holds no aligned frame).
 // HBM-bound byte work: one thread per destination pixel, 4 x 3 source bytes in, 3 bytes out; a clip is ~5 MB.
 #include "af_common.h"
+#include <cmath>
 #include <string.h>
 
 namespace af {
@@ -107,6 +108,59 @@ extern "C" int af_warp_affine_clip_u8(const void* crops, const af_align_frame* f
 // Host helper of the aligner: copies n rectangles of uint8 rows into one (pinned) staging buffer - memcpy per row, no device work.
 // The Python caller cut each crop to the rows / columns the warp can sample; numpy copies such a strided view with ~100 ns of
 // iterator overhead per row (8 000 rows per clip: half of the aligner call).  ctypes releases the GIL for the call.
+extern "C" int af_align_plan_u8(const af_align_crop* crops, int n, int canvas_h, int canvas_w, const double* tfm, int size,
+                                af_stage_rect* rects, af_align_frame* frames, int64_t* total_bytes, int32_t* bad_frame) {
+    using namespace af;
+    AF_REQUIRE(crops && n >= 0 && tfm && size > 0 && rects && frames && total_bytes, "align_plan_u8: bad argument");
+    if (bad_frame) *bad_frame = -1;
+    // the rectangle of the canvas the destination square can sample: dst = M [x y 1]^T  ->  src = M^-1 (dst - t) at its four corners
+    const double det = tfm[0] * tfm[4] - tfm[1] * tfm[3];
+    bool cut = std::isfinite(det) && std::fabs(det) >= 1e-12;      // singular map: OpenCV's D = 0 path samples around one point; keep everything
+    long long ylo = 0, yhi = 0;
+    if (cut) {
+        const double s = (double)(size - 1), cx[4] = {0.0, s, 0.0, s}, cy[4] = {0.0, 0.0, s, s};
+        double ymin = 0.0, ymax = 0.0;
+        for (int k = 0; k < 4; ++k) {
+            const double dx = cx[k] - tfm[2], dy = cy[k] - tfm[5];
+            const double xs = (tfm[4] * dx - tfm[1] * dy) / det, ys = (-tfm[3] * dx + tfm[0] * dy) / det;
+            if (!std::isfinite(xs) || !std::isfinite(ys)) { cut = false; break; }
+            if (k == 0 || ys < ymin) ymin = ys;
+            if (k == 0 || ys > ymax) ymax = ys;
+        }
+        if (cut) { ylo = (long long)std::floor(ymin) - 3; yhi = (long long)std::ceil(ymax) + 4; }
+    }
+    int64_t total = 0;
+    for (int i = 0; i < n; ++i) {
+        const af_align_crop& c = crops[i];
+        AF_REQUIRE(c.src && c.h > 0 && c.w > 0 && c.pitch >= (int64_t)c.w * 3, "align_plan_u8: bad crop %d", i);
+        if (c.x < 0 || c.y < 0 || (long long)c.x + c.w > canvas_w || (long long)c.y + c.h > canvas_h) {
+            if (bad_frame) *bad_frame = i;
+            return set_error(AF_ERR_ARG, "aligner: frame %d (%dx%d at %d,%d) does not fit the %dx%d canvas", i, c.w, c.h, c.x, c.y, canvas_w, canvas_h);
+        }
+        long long r0 = 0, r1 = c.h;
+        if (cut) {
+            r0 = ylo - c.y > 0 ? ylo - c.y : 0;
+            r1 = yhi - c.y < c.h ? yhi - c.y : c.h;
+        }
+        int iw = c.w;
+        if (r1 <= r0) { r0 = 0; r1 = 1; iw = 1; }                   // the warp never reaches this crop: one pixel keeps the frame table valid
+        rects[i].src = (const char*)c.src + r0 * c.pitch;
+        rects[i].dst_offset = total;
+        rects[i].src_pitch = c.pitch;
+        rects[i].rows = (int32_t)(r1 - r0);
+        rects[i].row_bytes = iw * 3;
+        if (rects[i].rows == 1) rects[i].src_pitch = rects[i].row_bytes;
+        frames[i].offset = total;
+        frames[i].ih = (int32_t)(r1 - r0);
+        frames[i].iw = iw;
+        frames[i].x = c.x;
+        frames[i].y = (int32_t)(c.y + r0);
+        total += ((int64_t)(r1 - r0) * iw * 3 + 15) / 16 * 16;
+    }
+    *total_bytes = total;
+    return AF_OK;
+}
+
 extern "C" int af_stage_rows_u8(void* dst, const af_stage_rect* rects, int n) {
     using namespace af;
     AF_REQUIRE(dst && rects && n >= 0, "stage_rows_u8: bad argument");

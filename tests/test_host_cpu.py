@@ -231,15 +231,22 @@ def test_kernel_selection_and_workspace_sizing_are_host_logic():
     assert name(s4b(16, 0)).startswith("conv_igemm")                                            # fp32: generic kernel
     assert name(_desc(16, 16, 28, 28, 128, 128, (1, 3, 3), (1, 2, 2), (0, 1, 1))).startswith("conv_igemm")   # stride 2
     assert name(_desc(16, 32, 56, 56, 64, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1))).startswith("conv133_c64")
-    # the long-K `a` convs of s4 (positions = a multiple of 49: 14x14 frames): 224-row tiles = 224 workgroups instead of 196
-    s4a = _desc(16, 16, 14, 14, 1024, 256, (3, 1, 1), (1, 1, 1), (1, 0, 0))
+    # round 4: the 3x1x1 `a` convs of s3 / s4 take the patch-resident kernel's temporal mode at bench batch sizes (>= 192 units of
+    # (clip, P pixels, all frames)); one clip, fp32 and 512 output channels (s5) do not
+    t311 = lambda n, hw, cin, cout, dt=1: _desc(n, 16, hw, hw, cin, cout, (3, 1, 1), (1, 1, 1), (1, 0, 0), dt)
+    assert name(t311(16, 14, 1024, 256)).startswith("conv311g") and name(t311(16, 28, 512, 128)).startswith("conv311g")
+    assert name(t311(16, 56, 256, 128)).startswith("conv311g") and name(t311(16, 28, 512, 256)).startswith("conv311g")
+    assert not name(t311(1, 14, 1024, 256)).startswith("conv311g") and not name(t311(16, 14, 1024, 256, 0)).startswith("conv311g")
+    assert name(t311(16, 7, 2048, 512)).startswith("conv_igemm")
+    # the long-K 1x1x1 `a` convs of s4 (positions = a multiple of 49: 14x14 frames): 224-row tiles = 224 workgroups instead of 196
+    s4a = _desc(16, 16, 14, 14, 1024, 256, (1, 1, 1), (1, 1, 1), (0, 0, 0))
     assert name(s4a) == "conv_igemm<BN=256,BM=224>"
     os.environ["AF_IGEMM_224"] = "0"
     try:
         assert name(s4a) == "conv_igemm<BN=256,BM=256>"
     finally:
         del os.environ["AF_IGEMM_224"]
-    assert name(_desc(16, 16, 16, 16, 1024, 256, (3, 1, 1), (1, 1, 1), (1, 0, 0))) == "conv_igemm<BN=256,BM=256>"   # 65 536 positions
+    assert name(_desc(16, 16, 16, 16, 1024, 256, (1, 1, 1), (1, 1, 1), (0, 0, 0))) == "conv_igemm<BN=256,BM=256>"   # 65 536 positions
     # split-K scratch: one clip in s4 / s5 splits, a full batch does not
     assert L.af_conv_workspace_bytes(C.byref(s4b(1))) > 0 and L.af_conv_workspace_bytes(C.byref(s4b(16))) == 0
     s5b = _desc(1, 16, 7, 7, 512, 512, (1, 3, 3), (1, 1, 1), (0, 1, 1))
@@ -460,3 +467,44 @@ def test_stage_rows_host_helper_matches_numpy():
         assert np.array_equal(dst[o:o + v.size].reshape(v.shape), v)
     bad = (_lib.StageRect * 1)(_lib.StageRect(views[1].ctypes.data, 0, 10, 4, 138))
     assert _lib.lib.af_stage_rows_u8(C.c_void_p(dst.ctypes.data), bad, 1) != 0
+
+
+def test_align_plan_host_helper_matches_the_python_path():
+    """af_align_plan_u8 is host code (round 4: the aligner's per-frame planning - canvas fit, row cut, staging table, frame table - as
+    one C call): same tables as the Python path it replaces (FasterCropAlignXRay._clip_rect + _layout + launch_warps' frame table)
+    for a random clip, for a singular transform (nothing is cut), and the reference's ValueError case (a crop that sticks out)."""
+    import ctypes as C
+    import numpy as np
+    from af_mi355x import _lib, aligner
+    rng = np.random.default_rng(3)
+    n, H, W = 9, 300, 280
+    images, diff = [], []
+    for i in range(n):
+        ih, iw = int(rng.integers(120, 200)), int(rng.integers(100, 180))
+        images.append(rng.integers(0, 256, size=(ih, iw, 3), dtype=np.uint8))
+        diff.append((int(rng.integers(0, W - iw)), int(rng.integers(0, H - ih))))
+    diff = np.array(diff, dtype=np.int64)
+    al = aligner.FasterCropAlignXRay.__new__(aligner.FasterCropAlignXRay)
+    al.image_size = 224
+    for tfm in (np.array([[0.9, 0.2, -30.0], [-0.2, 0.9, 10.0]]), np.array([[1.0, 2.0, 3.0], [2.0, 4.0, 5.0]])):   # regular, singular
+        cut, shapes, d2 = al._clip_rect(images, diff, tfm)
+        offs, total = aligner.FasterCropAlignXRay._layout(cut)
+        crops = (_lib.AlignCrop * n)(*[_lib.AlignCrop(im.ctypes.data, im.strides[0], im.shape[0], im.shape[1], int(diff[i][0]), int(diff[i][1]))
+                                       for i, im in enumerate(images)])
+        rects, frames = (_lib.StageRect * n)(), (_lib.AlignFrame * n)()
+        tot, bad = C.c_int64(0), C.c_int32(-1)
+        m = (C.c_double * 6)(*tfm.reshape(6).tolist())
+        _lib.check(_lib.lib.af_align_plan_u8(crops, n, H, W, m, 224, rects, frames, C.byref(tot), C.byref(bad)), "align_plan_u8")
+        assert tot.value == total and bad.value == -1
+        for i in range(n):
+            assert (frames[i].offset, frames[i].ih, frames[i].iw, frames[i].x, frames[i].y) == (offs[i], shapes[i][0], shapes[i][1], int(d2[i][0]), int(d2[i][1]))
+            assert (rects[i].dst_offset, rects[i].rows, rects[i].row_bytes) == (offs[i], shapes[i][0], shapes[i][1] * 3)
+            assert rects[i].src == cut[i].ctypes.data
+        # ... and the staged bytes are the same picture
+        dst = np.zeros(total, dtype=np.uint8)
+        _lib.check(_lib.lib.af_stage_rows_u8(C.c_void_p(dst.ctypes.data), rects, n), "stage_rows_u8")
+        for i in range(n):
+            assert (dst[offs[i]:offs[i] + cut[i].size] == np.ascontiguousarray(cut[i]).reshape(-1)).all()
+    crops[4].x = W - images[4].shape[1] + 1                                    # one pixel over the right edge of the canvas
+    rc = _lib.lib.af_align_plan_u8(crops, n, H, W, m, 224, rects, frames, C.byref(tot), C.byref(bad))
+    assert rc != 0 and bad.value == 4
