@@ -99,6 +99,7 @@ class _StagingRing:
 # clips/s host-inclusive, rows + columns 1 020-1 100 - 22 % fewer bytes, but 8 000 short strided memcpys per clip run far below the
 # rate of 32 long ones.  Off; AF_ALIGN_COLS=1 switches it on for A/B runs.
 _CLIP_COLUMNS = os.environ.get("AF_ALIGN_COLS", "0") == "1"
+_PLAN_IN_C = os.environ.get("AF_ALIGN_PLAN", "1") == "1"        # 0: the per-frame planning in Python (round 3), for A/B runs
 _COPY_THREADS = 2          # measured on the MI355X host: 1 thread 45 GB/s, 2 threads 72 GB/s, 4+ slower (memory-bound copies)
 _copy_pool = None
 
@@ -163,7 +164,7 @@ class FasterCropAlignXRay:
         out = torch.empty((len(images), self.image_size, self.image_size, 3), dtype=torch.uint8, device=dev)
         if len(images) == 0:
             return out
-        if not _CLIP_COLUMNS:
+        if not _CLIP_COLUMNS and _PLAN_IN_C:
             return self._warp_clip_planned(images, diff, h, w, tfm, out, dev)
         # only the part of a crop the warp can touch is uploaded: the destination square maps to a parallelogram of the canvas;
         # a crop cut to rows [r0, r1) x columns [c0, c1) is the same picture as that smaller crop pasted (c0, r0) further in

@@ -644,7 +644,8 @@ static int conv311g_pixels(const af_conv_desc* d) {
     if (d->t < 4 || mpad % d->t != 0) return 0;
     const int P = mpad / d->t;
     const int prows = ((d->t + 2) * P + 7) & ~7;
-    if (P < 7 || prows > 576 || 2 * prows * 128 + 2 * d->cout * 128 + (d->cout == 128 ? prows * 4 : 0) > 160 * 1024) return 0;
+    // (patch rows: 64 per DMA piece of a wave - 5 pieces in the 256-channel instantiation, 9 in the 128-channel one)
+    if (P < 7 || prows > (d->cout == 256 ? 320 : 576) || 2 * prows * 128 + 2 * d->cout * 128 + (d->cout == 128 ? prows * 4 : 0) > 160 * 1024) return 0;
     const long long hw = (long long)d->h * d->w, chunks = (hw + P - 1) / P, units = (long long)d->n * chunks;
     if (units < 192 || units > 0x7fffffffLL) return 0;
     if ((double)hw / ((double)chunks * P) < 0.6) return 0;                       // most positions of a unit are real

@@ -238,6 +238,9 @@ def test_kernel_selection_and_workspace_sizing_are_host_logic():
     assert name(t311(16, 56, 256, 128)).startswith("conv311g") and name(t311(16, 28, 512, 256)).startswith("conv311g")
     assert not name(t311(1, 14, 1024, 256)).startswith("conv311g") and not name(t311(16, 14, 1024, 256, 0)).startswith("conv311g")
     assert name(t311(16, 7, 2048, 512)).startswith("conv_igemm")
+    # SlowFast's Slow pathway at bench size (T = 4: P = 56, a (4 + 2) x 56 = 336-row patch) is more than the five DMA pieces per wave of
+    # the 256-channel instantiation cover: the predicate must say no (round 4: it said yes and the bench's launch failed)
+    assert not name(_desc(16, 4, 28, 28, 512, 256, (3, 1, 1), (1, 1, 1), (1, 0, 0))).startswith("conv311g")
     # the long-K 1x1x1 `a` convs of s4 (positions = a multiple of 49: 14x14 frames): 224-row tiles = 224 workgroups instead of 196
     s4a = _desc(16, 16, 14, 14, 1024, 256, (1, 1, 1), (1, 1, 1), (0, 0, 0))
     assert name(s4a) == "conv_igemm<BN=256,BM=224>"
