@@ -32,7 +32,30 @@ struct C133Args {
     int H, W, frames;
     int strips_per_frame, total_strips;
     int rows_alloc;      // LDS rows per patch buffer (multiple of 8)
+#ifdef AF_STAMPS
+    unsigned long long* stamps;   // diagnostic build only (tools/stamps_lib.sh): [workgroup][wave][8] shader-clock cycles per phase
+    int dbg;                      // timing-only ablations (AF_C64_DBG; outputs are then garbage): 1 no tile stores, 2 no epilogue, 4 no patch DMA
+#endif
 };
+
+// Diagnostic build (-DAF_STAMPS; never the shipped library): cycles of a wave's life by phase, summed over its strips.
+// (s_memtime waits with lgkmcnt(0): the stamps sit where no LDS read is meant to stay in flight.)
+#ifdef AF_STAMPS
+#define C64_ACC_DECL unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = __builtin_amdgcn_s_memtime()
+#define C64_ACC(slot) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[slot] += t_ - st_prev; st_prev = t_; } while (0)
+#ifdef C64_CT_DBG
+#define C64_DBG(bit) ((C64_CT_DBG) & (bit))       // compile-time ablations: no branch left in the loop
+#else
+#define C64_DBG(bit) (a.dbg & (bit))
+#endif
+#define C64_FLUSH do { if (a.stamps && lane < 8) a.stamps[((long long)blockIdx.x * 8 + wave) * 8 + lane] = \
+    lane == 0 ? st_acc[0] : lane == 1 ? st_acc[1] : lane == 2 ? st_acc[2] : lane == 3 ? st_acc[3] : lane == 4 ? st_acc[4] : lane == 5 ? st_acc[5] : lane == 6 ? st_acc[6] : st_acc[7]; } while (0)
+#else
+#define C64_ACC_DECL do {} while (0)
+#define C64_ACC(slot) do {} while (0)
+#define C64_DBG(bit) false
+#define C64_FLUSH do {} while (0)
+#endif
 
 
 template <int DT, int R>
@@ -228,28 +251,52 @@ __global__ __launch_bounds__(512, 2) void conv133_c64x2_kernel(const C133Args a)
     const int NP = a.rows_alloc >> 3;
     const int buf_bytes = a.rows_alloc * 128;
     char* otile = reinterpret_cast<char*>(smem) + 2 * buf_bytes;
+    C64_ACC_DECL;
 
     // ---- this wave's 32 output channels of the weights -> registers
     // (taps 0-6 in registers: 112; the last two taps' fragments wait in LDS in fragment order - 144 + accumulators + fragments +
     //  the store / DMA temporaries spilled 22 registers, and a scratch reload's vmcnt(0) also waits for the patch DMA in flight)
     constexpr int RT = 7;                                        // taps whose weights live in registers
+    // Round 4: the weights come in through LDS.  As 28 global loads per wave in fragment order (a wave instruction = 16 rows x 64
+    // bytes, every wave of every workgroup asking for the same 73 KB at the same moment) the prologue took 16-22 k cycles of a
+    // workgroup's ~240 k (in-kernel stamps) - ~14 bytes per clock and CU.  Now the [64][9][64] tensor is ONE coalesced LDS-DMA image
+    // per workgroup (72 pieces of 8 x 128 bytes, rows swizzled like the patches, in the patch buffers' space), every wave takes its
+    // fragments from there, and the first patch is issued once everyone has.
     u32x4 wreg[RT][2][NT2];
-#pragma unroll
-    for (int tap = 0; tap < RT; ++tap)
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int i = 0; i < NT2; ++i) {
-                const int ch = ng * 32 + i * 16 + frow;
-                wreg[tap][kk][i] = *reinterpret_cast<const u32x4*>(a.w + ((ch * 9 + tap) * 64 + kk * 32 + fg * 8) * 2);
-                asm volatile("" : "+v"(wreg[tap][kk][i]));
-            }
     float* bn_lds = reinterpret_cast<float*>(otile + OTROWS * 128);
-    if (tid < 64) { bn_lds[tid] = a.scale[tid]; bn_lds[64 + tid] = a.shift[tid]; }
     uint4* w8 = reinterpret_cast<uint4*>(bn_lds + 128);          // taps RT .. 8: [tap][k-half][channel tile 0..3][64 lanes]
-    for (int idx = tid; idx < (9 - RT) * 512; idx += 512) {
-        const int f = idx >> 6, tap = RT + (f >> 3), kk = (f >> 2) & 1, ct = f & 3;
-        w8[idx] = *reinterpret_cast<const uint4*>(a.w + (((ct * 16 + frow) * 9 + tap) * 64 + kk * 32 + fg * 8) * 2);
+    {
+        const i32x4 wdesc = make_desc(a.w);
+        const int wrow = lane >> 3, wchunk = (lane & 7) ^ wrow;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            const int g = wave + 8 * j;                          // rows 8 g .. 8 g + 7 of the 576 (channel, tap) rows
+            blds16((unsigned)((g * 8 + wrow) * 128 + wchunk * 16), wdesc, 0, __builtin_amdgcn_readfirstlane(lds0 + g * 1024));
+        }
+        if (tid < 64) { bn_lds[tid] = a.scale[tid]; bn_lds[64 + tid] = a.shift[tid]; }
+        wait_vmcnt<0>();
+        __syncthreads();
+        const uint4* wimg = smem;
+        auto frag = [&](int ch, int tap, int kk) {               // 8 input channels kk * 32 + fg * 8 .. of (output channel ch, tap)
+            const int row = ch * 9 + tap;
+            return wimg[row * 8 + ((kk * 4 + fg) ^ (row & 7))];
+        };
+#pragma unroll
+        for (int tap = 0; tap < RT; ++tap)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < NT2; ++i) wreg[tap][kk][i] = __builtin_bit_cast(u32x4, frag(ng * 32 + i * 16 + frow, tap, kk));
+        for (int idx = tid; idx < (9 - RT) * 512; idx += 512) {
+            const int f = idx >> 6, tap = RT + (f >> 3), kk = (f >> 2) & 1, ct = f & 3;
+            w8[idx] = frag(ct * 16 + frow, tap, kk);
+        }
+#pragma unroll
+        for (int tap = 0; tap < RT; ++tap)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < NT2; ++i) asm volatile("" : "+v"(wreg[tap][kk][i]));    // (registers for good: no re-reads inside the loop)
     }
 
     unsigned* dma_tab = reinterpret_cast<unsigned*>(w8 + (9 - RT) * 512);
@@ -274,10 +321,12 @@ __global__ __launch_bounds__(512, 2) void conv133_c64x2_kernel(const C133Args a)
     const int G = gridDim.x, b = blockIdx.x;
     const int s0 = (int)((long long)a.total_strips * b / G), s1 = (int)((long long)a.total_strips * (b + 1) / G);
     if (s0 < s1) issue_patch(s0, 0);
+    C64_ACC(0);                                                      // 0: prologue (weights, tables, first patch issue)
     auto store_tile = [&](int sp) {
         const int frame = sp / a.strips_per_frame;
         const int h0 = (sp - frame * a.strips_per_frame) * R;
         char* obase = a.out + ((long long)frame * a.H + h0) * a.W * 128;
+        if (C64_DBG(1)) return;
 #pragma unroll
         for (int j = 0; j < OTROWS * 8 / 512; ++j) {
             const int row = (tid + 512 * j) >> 3, chunk = tid & 7, r = row / WP, c = row - r * WP;
@@ -291,8 +340,11 @@ __global__ __launch_bounds__(512, 2) void conv133_c64x2_kernel(const C133Args a)
     for (int s = s0; s < s1; ++s) {
         const int buf = (s - s0) & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        C64_ACC(1);                                                  // 1: wait for the patch DMA (and the tile stores)
         __builtin_amdgcn_s_barrier();
-        if (s + 1 < s1) issue_patch(s + 1, buf ^ 1);
+        C64_ACC(2);                                                  // 2: barrier
+        if (s + 1 < s1 && !C64_DBG(4)) issue_patch(s + 1, buf ^ 1);
+        C64_ACC(3);                                                  // 3: next patch issue
 
         const char* xb = reinterpret_cast<const char*>(smem) + buf * buf_bytes;
         f32x4 acc[NT2][MT];
@@ -340,7 +392,10 @@ __global__ __launch_bounds__(512, 2) void conv133_c64x2_kernel(const C133Args a)
             sf[i] = *reinterpret_cast<const f32x4*>(bn_lds + 64 + ng * 32 + i * 16 + fg * 4);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        C64_ACC(4);                                                  // 4: the 144 MFMAs (+ the previous tile's stores at step 6)
         __builtin_amdgcn_s_barrier();
+        C64_ACC(5);                                                  // 5: barrier (everyone has read the previous tile out)
+        if (!C64_DBG(2)) {
 #pragma unroll
         for (int k = 0; k < MT; ++k) {
             const int row = (mg + 4 * k) * 16 + frow;
@@ -352,14 +407,25 @@ __global__ __launch_bounds__(512, 2) void conv133_c64x2_kernel(const C133Args a)
                 Vec4<DT>::store(otile + row * 128 + (((ch >> 3) ^ (row & 7)) << 4) + (ch & 4) * 2, v);
             }
         }
+        }
+        C64_ACC(6);                                                  // 6: epilogue
     }
     if (s0 < s1) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         store_tile(s1 - 1);
     }
+    C64_ACC(7);
+    C64_FLUSH;
 }
 
+// Round 4, tried and NOT kept (DESIGN 3.1b has the stamp tables): a "skewed" form of this kernel - waves 4-7 taking the strip's one
+// barrier in the middle of their strip (three patch slots), DMA pieces issued one per tap-step with computed offsets, no output tile
+// (register epilogue: permlane16 swaps + four counted 16-byte buffer stores per wave and strip).  Parity green, 129-135 us against
+// 120-128 for this form; with the skew switched off 122-127: a tie.  What the stamps showed instead is where this form's time is:
+// the MFMA phase of the two waves of a SIMD is MFMA-bound while both multiply (5.0-5.4 k cycles per strip for 288 MFMAs), the older
+// wave of the two wins the issue arbitration and the younger one starves until it is alone, and alone a wave with one tap-step of
+// LDS look-ahead runs at ~25 cycles per MFMA - so putting one wave's epilogue under the other's MFMAs buys what the lone stretches lose.
 template <int DT>
 static int launch_c133(C133Args& a, hipStream_t stream) {
     constexpr int R = 4;
@@ -398,6 +464,12 @@ int conv133_run(const af_conv_desc* d, const void* in, const void* w_packed, con
     C133Args a;
     a.in = (const char*)in; a.w = (const char*)w_packed; a.scale = scale; a.shift = shift; a.out = (char*)out;
     a.H = d->h; a.W = d->w; a.frames = d->n * d->t;
+#ifdef AF_STAMPS
+    const char* ep = getenv("AF_STAMP_PTR");
+    a.stamps = ep ? (unsigned long long*)strtoull(ep, nullptr, 0) : nullptr;
+    const char* ed = getenv("AF_C64_DBG");
+    a.dbg = ed ? atoi(ed) : 0;
+#endif
     return d->dtype == AF_BF16 ? launch_c133<AF_BF16>(a, stream) : launch_c133<AF_F16>(a, stream);
 }
 

@@ -192,6 +192,10 @@ CONV_CASES = [
     # of 4 rows); narrower frames take the generic kernel (case "1x3x3" above)
     ("c64_1x3x3_56x56", 64, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 5, 56, 56), True, False),
     ("c64_1x3x3_30x27", 64, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), (2, 3, 30, 27), True, False),
+    # ... and with several strips per workgroup (round 4's skewed form: a three-slot patch ring that wraps, one barrier per strip,
+    # the two channel halves half a strip apart): 7 strips per workgroup at 56 x 56, 4-5 at a ragged 54 x 50
+    ("c64_1x3x3_56x56_many", 64, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), (4, 32, 56, 56), True, False),
+    ("c64_1x3x3_54x50_many", 64, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), (3, 27, 54, 50), True, False),
     ("3x3x3_synthetic", 64, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 4, 9, 10), True, False),
     ("5x1x1_t_stride8", 64, 128, (5, 1, 1), (8, 1, 1), (2, 0, 0), (1, 32, 4, 5), True, False),
     ("big_m_tail", 64, 64, (1, 1, 1), (1, 1, 1), (0, 0, 0), (3, 7, 17, 19), False, False),
@@ -256,7 +260,8 @@ CONV_CASES = [
     ("t311g_64to128_T16_ragged", 64, 128, (3, 1, 1), (1, 1, 1), (1, 0, 0), (1, 16, 74, 73), True, False),
     ("t311g_128to128_T32_norelu", 128, 128, (3, 1, 1), (1, 1, 1), (1, 0, 0), (1, 32, 52, 52), False, False),
 ]
-EXPECT_VARIANT = {"c64_1x3x3_56x56": {"f16": 4, "bf16": 4}, "c64_1x3x3_30x27": {"f16": 4, "bf16": 4}, "1x3x3": {"f16": 3, "bf16": 3},
+EXPECT_VARIANT = {"c64_1x3x3_56x56": {"f16": 4, "bf16": 4}, "c64_1x3x3_30x27": {"f16": 4, "bf16": 4},
+                  "c64_1x3x3_56x56_many": {"f16": 4, "bf16": 4}, "c64_1x3x3_54x50_many": {"f16": 4, "bf16": 4}, "1x3x3": {"f16": 3, "bf16": 3},
                   "tile256_1x3x3_res": 6, "tile256_ragged_m": 6, "tile224_1x3x3_res": 12, "tile224_ragged_m": 12,
                   "tile224_3x1x1_1024to256": {"f16": 12, "bf16": 12}, "tile224_1x1x1_1024to256_res": {"f16": 12, "bf16": 12}, "tile512_1x3x3_res": 7, "tile512_ragged_m": 7,
                   "t311_64to64_T32": 8, "t311_256to64_T16": 8, "t311_256to64_T32_many": 8,
