@@ -306,6 +306,11 @@ template <> struct Vec4<AF_BF16> {
         f32x4 o; o[0] = (float)i[0]; o[1] = (float)i[1]; o[2] = (float)i[2]; o[3] = (float)i[3];
         return o;
     }
+    static __device__ __forceinline__ f32x4 unpack(unsigned __attribute__((ext_vector_type(2))) raw) {   // 8 bytes read earlier
+        b4 i = __builtin_bit_cast(b4, raw);
+        f32x4 o; o[0] = (float)i[0]; o[1] = (float)i[1]; o[2] = (float)i[2]; o[3] = (float)i[3];
+        return o;
+    }
 };
 // Two MFMA accumulator tiles (lane = 4 consecutive channels of position frow, k-group fg) -> 16 contiguous bytes per lane
 // without LDS: v_permlane16_swap_b32 (gfx950) exchanges the odd 16-lane rows of its first operand with the even rows of the second,
@@ -333,6 +338,11 @@ template <> struct Vec4<AF_F16> {
     }
     static __device__ __forceinline__ f32x4 load(const void* p) {
         h4 i = *reinterpret_cast<const h4*>(p);
+        f32x4 o; o[0] = (float)i[0]; o[1] = (float)i[1]; o[2] = (float)i[2]; o[3] = (float)i[3];
+        return o;
+    }
+    static __device__ __forceinline__ f32x4 unpack(unsigned __attribute__((ext_vector_type(2))) raw) {
+        h4 i = __builtin_bit_cast(h4, raw);
         f32x4 o; o[0] = (float)i[0]; o[1] = (float)i[1]; o[2] = (float)i[2]; o[3] = (float)i[3];
         return o;
     }

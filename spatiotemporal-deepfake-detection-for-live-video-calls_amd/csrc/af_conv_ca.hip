@@ -16,6 +16,7 @@
 // the b fragments (K = 64: four 16-byte fragments per lane and tile) go global -> registers a stage / a tile ahead; BN
 // parameters sit in LDS (a plain global load between the DMA issue and its use would make hipcc wait for the DMA in flight).
 #include "af_common.h"
+#include <stdlib.h>
 
 namespace af {
 
@@ -34,18 +35,34 @@ struct CAArgs {
     char* outa;          // [N][T][HW][64]
     int T, HW, C, kslabs;
     int P, chunks, tiles;
+#ifdef AF_STAMPS
+    int dbg;             // diagnostic build only: timing-only ablations (AF_CA_DBG; outputs are then garbage): 1 no c-weight loads after
+                         // the first stage, 2 no b-fragment loads after the first tile, 4 no `a` output stores, 8 no trunk stores
+#endif
 };
+#ifdef AF_STAMPS
+#define CA_DBG(bit) (a.dbg & (bit))
+#else
+#define CA_DBG(bit) false
+#endif
 
 // DUAL: block 0 of a stage - x = relu(bn_c(c(b)) + bn_1(branch1(x0))) with the 1x1x1 projection shortcut as a second K segment
 // of the same accumulator (no residual tensor: the image rows are written, not updated; their padding frames are zeroed once).
-template <int DT, bool DUAL>
+// CWL (round 4, plain form): the c weights of a stage come in as ONE 8-KB LDS-DMA image per workgroup (a piece per wave) and every
+// wave takes its fragments from there.  Timing builds (tools/exp_ca_dbg.py): the eight fragment-order global loads per wave and
+// stage - the same 8 KB for all eight waves, 16 rows x 64 bytes per instruction - were 15 % of the launch (0.432 -> 0.374 ms
+// without them) although they add nothing to the HBM bytes: a memory instruction holds its wave for 200-300 cycles whatever it
+// fetches.  The 8 KB come from the padding frames: consecutive image slots now SHARE the zero rows between them ([Z][I0][Z][I1][Z][I2][Z],
+// zeroed once, never fetched - which also makes it exactly four image pieces per wave and stage).
+template <int DT, bool DUAL, bool CWL>
 __global__ __launch_bounds__(512, 2) void conv_ca_kernel(const CAArgs a) {
     typedef Elem<DT> E;
     static_assert(E::EPC == 8, "16-bit operands only");
     constexpr int BM = 256, TN = 4, TM = 2;
     constexpr int WROWS = 3 * 64;                      // a-weight rows per stage: (dt, channel)
     constexpr int WPIECES = WROWS / 64;                // weight DMA pieces per wave
-    constexpr int XPW = 5;                             // image pieces per wave (rows BM + 2P <= 288): 4 or 5 by wave
+    constexpr int XPW = 4;                             // image pieces per wave: the tile's 256 rows (the padding frames are never fetched)
+    static_assert(!(DUAL && CWL), "the projection form keeps both c weight sets in LDS anyway");
     constexpr int WBYTES = WROWS * 128;
 
     extern __shared__ uint4 smem[];
@@ -53,22 +70,26 @@ __global__ __launch_bounds__(512, 2) void conv_ca_kernel(const CAArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int frow = lane & 15, fg = lane >> 4;
-    const int P = a.P, XR = BM + 2 * P, XP = XR >> 3;
-    const int img_bytes = XR * 128;
+    const int P = a.P;
+    const int slot_bytes = (BM + P) * 128;             // a slot = its leading padding frame + the tile's rows; the trailing one is the next slot's
+    constexpr int NIMG = DUAL ? 1 : 3;
     // LDS: a-weight ring (2 slots) | image ring (3 slots: the residual slab is fetched TWO stages ahead - one stage in flight
-    // is ~56 KB per CU, which at the loaded HBM latency is 4 TB/s; two are what the stream needs) | BN parameters
+    // is ~56 KB per CU, which at the loaded HBM latency is 4 TB/s; two are what the stream needs) + one more padding frame |
+    // (CWL) the c weights of the stage | BN parameters
     char* sm = reinterpret_cast<char*>(smem);
     // (DUAL: no residual is fetched, the c conv WRITES the slab: one image buffer; the room goes to the two c weight sets,
     //  [C][64] each, resident in LDS for the life of the workgroup)
     char* img0 = sm + 2 * WBYTES;
-    char* wlds = img0 + (DUAL ? 1 : 3) * img_bytes;
+    const int img_all = NIMG * slot_bytes + P * 128;
+    char* cwl = img0 + img_all;                        // CWL: [64 channels][64 k], rows swizzled like the rings
+    char* wlds = cwl + (CWL ? 64 * 128 : 0);
     float* bnp = reinterpret_cast<float*>(wlds + (DUAL ? 2 * a.C * 128 : 0));     // scale_c[C] shift_c[C] scale_a[64] shift_a[64]
     const int wm = wave;                               // 32-row group of the tile
 
     for (int i = tid; i < a.C; i += 512) { bnp[i] = a.scale_c[i]; bnp[a.C + i] = a.shift_c[i]; }
-    if (DUAL) {                                        // no residual DMA ever touches the images: zero them (padding frames) once
+    {                                                  // the padding frames are zero for good: no DMA touches them, the c conv writes tile rows only
         uint4* z = reinterpret_cast<uint4*>(img0);
-        for (int i = tid; i < img_bytes / 16; i += 512) z[i] = uint4{0u, 0u, 0u, 0u};
+        for (int i = tid; i < img_all / 16; i += 512) z[i] = uint4{0u, 0u, 0u, 0u};
     }
     if (tid < 64) { bnp[2 * a.C + tid] = a.scale_a[tid]; bnp[2 * a.C + 64 + tid] = a.shift_a[tid]; }
 
@@ -86,12 +107,11 @@ __global__ __launch_bounds__(512, 2) void conv_ca_kernel(const CAArgs a) {
     int xp[XPW];
 #pragma unroll
     for (int i = 0; i < XPW; ++i) {
-        const int row = (wave + 8 * i) * 8 + drow;
-        const int t = row / P - 1, p = row % P;
+        const int row = (wave + 8 * i) * 8 + drow;                   // tile row = t * P + p
+        const int t = row / P, p = row % P;
         xp[i] = p;
-        xoff[i] = (t >= 0 && t < a.T && row < XR) ? (unsigned)((((long long)t * a.HW + p) * a.C) * 2 + chunk * 16) : kOutOfRange;
+        xoff[i] = (unsigned)((((long long)t * a.HW + p) * a.C) * 2 + chunk * 16);
     }
-    const bool five = wave + 8 * (XPW - 1) < XP;                     // this wave issues 5 image pieces per stage (else 4)
     const long long clipx = (long long)a.T * a.HW * a.C * 2, clipb = (long long)a.T * a.HW * 64 * 2;
 
     const int my_tiles = (a.tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
@@ -107,12 +127,15 @@ __global__ __launch_bounds__(512, 2) void conv_ca_kernel(const CAArgs a) {
     auto issue_image = [&](int g) {                                  // residual slab of stage g -> image slot g % 3
         const int tile = stage_tile(g), n = tile / a.chunks, hw0 = (tile % a.chunks) * P;
         const i32x4 xdesc = make_desc(a.res + n * clipx + (long long)hw0 * a.C * 2);
-        const unsigned base = lds0 + 2 * WBYTES + (g % 3) * img_bytes + wave * (8 * 128);
+        const unsigned base = lds0 + 2 * WBYTES + (g % 3) * slot_bytes + P * 128 + wave * (8 * 128);
         const int soff = (g % a.kslabs) * 128;
 #pragma unroll
         for (int i = 0; i < XPW; ++i)
-            if (wave + 8 * i < XP)
-                blds16_nt_m0(hw0 + xp[i] < a.HW ? xoff[i] : kOutOfRange, xdesc, soff, base + i * (64 * 128));
+            blds16_nt_m0(hw0 + xp[i] < a.HW ? xoff[i] : kOutOfRange, xdesc, soff, base + i * (64 * 128));
+    };
+    const i32x4 cdesc = make_desc(a.wc);
+    auto issue_cw = [&](int g) {                                     // CWL: c weights of stage g's slab, one piece (8 channels) per wave
+        blds16_m0((unsigned)((wave * 8 + drow) * 128 + chunk * 16), cdesc, (g % a.kslabs) * (64 * 128), lds0 + (unsigned)(cwl - sm) + wave * (8 * 128));
     };
     // c weights of a stage (4 channel tiles x 2 k-halves) and the b fragments of a tile (2 row tiles x 2 k-halves):
     // global -> registers, a stage / a tile ahead
@@ -145,7 +168,7 @@ __global__ __launch_bounds__(512, 2) void conv_ca_kernel(const CAArgs a) {
         for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     if (total > 0) {
-        if (!DUAL) load_wc(wnext, a.wc, 0);
+        if (!DUAL && !CWL) load_wc(wnext, a.wc, 0);
         load_b(bnext, a.inb, blockIdx.x);
         if (DUAL) {
             load_b(x0next, a.in1, blockIdx.x);
@@ -157,6 +180,7 @@ __global__ __launch_bounds__(512, 2) void conv_ca_kernel(const CAArgs a) {
             }
         }
         issue_weights(0);
+        if (CWL) issue_cw(0);
         if (!DUAL) {
             issue_image(0);
             if (total > 1) issue_image(1);
@@ -169,13 +193,19 @@ __global__ __launch_bounds__(512, 2) void conv_ca_kernel(const CAArgs a) {
         // stores of the previous iteration are still in flight (the 8 `a` output stores behind a tile's last slab are waited for:
         // once per tile, and the count does not depend on how hipcc emits them; leaving them in flight too measured no gain)
         if (q == 0) wait_vmcnt<0>();
-        else if (!DUAL && q + 1 < total) { if (five) wait_vmcnt<9>(); else wait_vmcnt<8>(); }
+        else if (!DUAL && q + 1 < total) wait_vmcnt<8>();
         else wait_vmcnt<4>();
         __builtin_amdgcn_s_barrier();                                // ... for everyone; weight slot (q+1)&1, image slot (q+2)%3 are free
         // (the c weights / b fragments are loads hipcc does not count - its own waits for them were vmcnt(7)..(0) at this point,
         //  which drained the image DMA issued behind them: ONE stage in flight instead of two; the empty asm orders the copies
         //  behind our wait)
-        if (!DUAL) {
+        if (CWL) {                                                   // this stage's c weights: fragments from the LDS image
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+                    wcur[i][kk] = *reinterpret_cast<const uint4*>(cwl + (i * 16 + frow) * 128 + (((kk * 4 + fg) ^ (frow & 7)) << 4));
+        } else if (!DUAL) {
 #pragma unroll
             for (int i = 0; i < TN; ++i)
 #pragma unroll
@@ -203,18 +233,18 @@ __global__ __launch_bounds__(512, 2) void conv_ca_kernel(const CAArgs a) {
         const bool last = c_kc + 1 == a.kslabs;
         if (q + 1 < total) {
             // plain loads BEFORE the DMA issue: hipcc's wait for them must not cover the DMA
-            if (!DUAL) load_wc(wnext, a.wc, last ? 0 : c_kc + 1);
-            if (last) {
+            if (!DUAL && !CWL && !CA_DBG(1)) load_wc(wnext, a.wc, last ? 0 : c_kc + 1);
+            if (last && !CA_DBG(2)) {
                 load_b(bnext, a.inb, c_tile + gridDim.x);
                 if (DUAL) load_b(x0next, a.in1, c_tile + gridDim.x);
             }
             __builtin_amdgcn_sched_barrier(0);
             issue_weights(q + 1);
-            if (!DUAL && q + 2 < total) issue_image(q + 2);
+            if (!DUAL && !CWL && q + 2 < total) issue_image(q + 2);
         }
         __builtin_amdgcn_sched_barrier(0);
         const int n = c_tile / a.chunks, hw0 = (c_tile % a.chunks) * P;
-        char* img = img0 + (DUAL ? 0 : q % 3) * img_bytes;           // image rows: (t + 1) * P + p
+        char* img = img0 + (DUAL ? 0 : q % 3) * slot_bytes;          // image rows: (t + 1) * P + p
         // ---- c conv, 64 trunk channels of this slab, in place: image = relu(bn_c(Wc b) + image)
         {
             f32x4 cc[TN][TM];
@@ -222,6 +252,28 @@ __global__ __launch_bounds__(512, 2) void conv_ca_kernel(const CAArgs a) {
             for (int i = 0; i < TN; ++i)
 #pragma unroll
                 for (int j = 0; j < TM; ++j) cc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // (round 4) the eight residual cells of this wave are read BEFORE the c conv's MFMAs and arrive under them: read where
+            // they are added, every cell was an LDS round trip of its own in front of its update - read, lgkmcnt(0), 25 vector
+            // operations, write, eight times per stage on an in-order wave
+            u32x2 rcell[TN][TM];
+            if (!DUAL) {
+#pragma unroll
+                for (int i = 0; i < TN; ++i)
+#pragma unroll
+                    for (int j = 0; j < TM; ++j) {
+                        const int R = P + wm * 32 + j * 16 + frow;
+                        rcell[i][j] = *reinterpret_cast<const u32x2*>(img + R * 128 + (((i * 2 + (fg >> 1)) ^ (frow & 7)) << 4) + (fg & 1) * 8);
+                    }
+            }
+            // ... and so are the BN parameters of channel tiles 0 and 1; those of tiles 2 and 3 are read into the same registers as
+            // soon as tiles 0 and 1 are done (two tiles of look-ahead instead of a round trip per tile)
+            f32x4 scv[2], sfv[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                scv[i] = *reinterpret_cast<const f32x4*>(bnp + c_kc * 64 + i * 16 + fg * 4);
+                sfv[i] = *reinterpret_cast<const f32x4*>(bnp + a.C + c_kc * 64 + i * 16 + fg * 4);
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 if (DUAL) {                                          // both weight slabs from their LDS images
@@ -242,22 +294,34 @@ __global__ __launch_bounds__(512, 2) void conv_ca_kernel(const CAArgs a) {
                         for (int j = 0; j < TM; ++j) Mma<DT>::run(wcur[i][kk], bcur[j][kk], cc[i][j]);
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < TN; ++i) {
-                const f32x4 sc = *reinterpret_cast<const f32x4*>(bnp + c_kc * 64 + i * 16 + fg * 4);
-                const f32x4 sf = *reinterpret_cast<const f32x4*>(bnp + a.C + c_kc * 64 + i * 16 + fg * 4);
+                const f32x4 sc = scv[i & 1], sf = sfv[i & 1];
 #pragma unroll
                 for (int j = 0; j < TM; ++j) {
                     const int R = P + wm * 32 + j * 16 + frow;       // image row of this position (R & 7 == frow & 7: P % 8 == 0)
                     char* cell = img + R * 128 + (((i * 2 + (fg >> 1)) ^ (frow & 7)) << 4) + (fg & 1) * 8;
                     f32x4 v = cc[i][j] * sc + sf;
-                    if (!DUAL) v += Vec4<DT>::load(cell);
+                    if (!DUAL) v += Vec4<DT>::unpack(rcell[i][j]);
                     Vec4<DT>::store_relu(cell, v);
                 }
+                if (i + 2 < TN) {
+                    scv[i & 1] = *reinterpret_cast<const f32x4*>(bnp + c_kc * 64 + (i + 2) * 16 + fg * 4);
+                    sfv[i & 1] = *reinterpret_cast<const f32x4*>(bnp + a.C + c_kc * 64 + (i + 2) * 16 + fg * 4);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                                // the slab of x is complete (raw barrier: the DMA stays in flight)
+        if (CWL && q + 1 < total) {
+            // everyone has its fragments of this stage's c weights: the next stage's go in - in FRONT of image(q + 2), so that the
+            // counted wait at the top of the next stage (which must cover them) still leaves that image in flight
+            if (!CA_DBG(1)) issue_cw(q + 1);
+            if (q + 2 < total) issue_image(q + 2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         // ---- the finished slab leaves for HBM as whole 128-byte row segments
         {
             char* ox = a.outx + ((long long)n * a.T * a.HW + hw0) * a.C * 2 + c_kc * 128;
@@ -266,7 +330,7 @@ __global__ __launch_bounds__(512, 2) void conv_ca_kernel(const CAArgs a) {
                 const int row = (tid >> 3) + 64 * it, ck = tid & 7;
                 const int t = row / P, p = row - t * P;
                 const u32x4 o = *reinterpret_cast<const u32x4*>(img + (P + row) * 128 + ((ck ^ ((P + row) & 7)) << 4));
-                if (hw0 + p < a.HW)
+                if (hw0 + p < a.HW && !CA_DBG(8))
                     __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(ox + ((long long)t * a.HW + p) * a.C * 2 + ck * 16));
             }
         }
@@ -318,7 +382,7 @@ __global__ __launch_bounds__(512, 2) void conv_ca_kernel(const CAArgs a) {
                 }
                 const u32x4 o = swap_pair16(half[0], half[1]);
                 const int ch = (2 * ip + (fg & 1)) * 16 + (fg >> 1) * 8;
-                if (hw0 + p < a.HW) *reinterpret_cast<u32x4*>(a.outa + (pos * 64 + ch) * 2) = o;
+                if (hw0 + p < a.HW && !CA_DBG(4)) *reinterpret_cast<u32x4*>(a.outa + (pos * 64 + ch) * 2) = o;
             }
         }
         c_kc = 0; c_tile += gridDim.x;
@@ -326,16 +390,16 @@ __global__ __launch_bounds__(512, 2) void conv_ca_kernel(const CAArgs a) {
 }
 
 // dynamic LDS of a launch: a-weight ring (2 slots) + image slot(s) (+ both c-side weight sets, DUAL) + the BN parameters
-static long long conv_ca_lds_bytes(bool dual, int P, int C) {
-    return 2LL * 3 * 64 * 128 + (dual ? (256LL + 2 * P) * 128 + 2LL * C * 128 : 3LL * (256 + 2 * P) * 128) + (2LL * C + 128) * 4;
+static long long conv_ca_lds_bytes(bool dual, int P, int C, bool cwl = false) {
+    return 2LL * 3 * 64 * 128 + (dual ? (256LL + 2 * P) * 128 + 2LL * C * 128 : (3LL * (256 + P) + P) * 128 + (cwl ? 64 * 128 : 0)) + (2LL * C + 128) * 4;
 }
 
-template <int DT, bool DUAL>
+template <int DT, bool DUAL, bool CWL>
 static int launch_ca(const CAArgs& a, int blocks, hipStream_t stream) {
-    const int lds = (int)conv_ca_lds_bytes(DUAL, a.P, a.C);
+    const int lds = (int)conv_ca_lds_bytes(DUAL, a.P, a.C, CWL);
     if (lds > 160 * 1024) return set_error(AF_ERR_ARG, "conv_ca: %d bytes of LDS needed", lds);
-    AF_SET_MAX_LDS((&conv_ca_kernel<DT, DUAL>), 160 * 1024, "conv_ca");
-    hipLaunchKernelGGL((conv_ca_kernel<DT, DUAL>), dim3(blocks), dim3(512), lds, stream, a);
+    AF_SET_MAX_LDS((&conv_ca_kernel<DT, DUAL, CWL>), 160 * 1024, "conv_ca");
+    hipLaunchKernelGGL((conv_ca_kernel<DT, DUAL, CWL>), dim3(blocks), dim3(512), lds, stream, a);
     AF_CHECK_LAUNCH("conv_ca_kernel");
     return AF_OK;
 }
@@ -377,10 +441,18 @@ int conv_ca_run(const af_conv_desc* dc, const void* inb, const void* wc, const v
     a.outx = (char*)outx; a.wa = (const char*)wa; a.scale_a = scale_a; a.shift_a = shift_a; a.outa = (char*)outa;
     a.T = dc->t; a.HW = dc->h * dc->w; a.C = dc->cout; a.kslabs = dc->cout / 64;
     a.P = 256 / dc->t; a.chunks = (a.HW + a.P - 1) / a.P; a.tiles = dc->n * a.chunks;
+#ifdef AF_STAMPS
+    const char* ed = getenv("AF_CA_DBG");
+    a.dbg = ed ? atoi(ed) : 0;
+#endif
     const int cus = device_cus();
     const int blocks = a.tiles < cus ? a.tiles : cus;
-    if (in1) return dc->dtype == AF_BF16 ? launch_ca<AF_BF16, true>(a, blocks, stream) : launch_ca<AF_F16, true>(a, blocks, stream);
-    return dc->dtype == AF_BF16 ? launch_ca<AF_BF16, false>(a, blocks, stream) : launch_ca<AF_F16, false>(a, blocks, stream);
+    if (in1) return dc->dtype == AF_BF16 ? launch_ca<AF_BF16, true, false>(a, blocks, stream) : launch_ca<AF_F16, true, false>(a, blocks, stream);
+    // the stage's c weights as an LDS image where its 8 KB fit (T = 32 with a 256-channel trunk; AF_CA_CWL=0: the fragment loads, for A/B runs)
+    const char* ecw = getenv("AF_CA_CWL");
+    if (conv_ca_lds_bytes(false, a.P, a.C, true) <= 160 * 1024 && !(ecw && atoi(ecw) == 0))
+        return dc->dtype == AF_BF16 ? launch_ca<AF_BF16, false, true>(a, blocks, stream) : launch_ca<AF_F16, false, true>(a, blocks, stream);
+    return dc->dtype == AF_BF16 ? launch_ca<AF_BF16, false, false>(a, blocks, stream) : launch_ca<AF_F16, false, false>(a, blocks, stream);
 }
 
 }  // namespace af

@@ -18,7 +18,7 @@ def timed(fn, n=20):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
 with torch.inference_mode():
-    for b in (16, 8, 4, 2, 1):
+    for b in (16, 16):
         xs = [x[i:i + b] for i in range(0, 16, b)]
         clf(xs[0])
         eng = clf.network._engines[("bf16", b, (32, 224, 224))]
