@@ -16,7 +16,7 @@ units = 256
 buf = torch.zeros(units * 8 * 8, dtype=torch.int64, device="cuda")
 os.environ["AF_STAMP_PTR"] = hex(buf.data_ptr())
 names = ["prologue", "vmcnt", "barrier1", "issue", "mfma", "barrier2", "epilogue", "tail"]
-for form, dbg in (("8", 0), ("8", 0), ("8", 1), ("8", 4), ("8", 5)):
+for form, dbg in (("8", 0), ("8", 0), ("8", 1), ("8", 2), ("8", 4), ("8", 7)):
     os.environ["AF_C64_DBG"] = str(dbg)
     os.environ["AF_C64_WAVES"] = form
     us = timeit(run, 200)
