@@ -936,12 +936,15 @@ def main():
                     for _ in range(3):
                         clf(xb)
                     torch.cuda.synchronize(dev)
-                    t0 = time.perf_counter()
-                    nrep = 30
-                    for _ in range(nrep):
-                        clf(xb)
-                    torch.cuda.synchronize(dev)
-                    lat[str(b)] = round(1e3 * (time.perf_counter() - t0) / nrep, 4)
+                    best, nrep = None, 20                       # best of three rounds: one host hiccup in a 30-step wall-clock loop once read 2.0 ms at B = 2 (1.27 re-measured)
+                    for _ in range(3):
+                        t0 = time.perf_counter()
+                        for _ in range(nrep):
+                            clf(xb)
+                        torch.cuda.synchronize(dev)
+                        dtb = (time.perf_counter() - t0) / nrep
+                        best = dtb if best is None else min(best, dtb)
+                    lat[str(b)] = round(1e3 * best, 4)
             line["latency_ms_by_batch"] = lat
         if args.cpu_clips > 0:
             n = min(args.cpu_clips, B)
