@@ -22,6 +22,7 @@
 // Temporal pool (tpool): tile = (clip, frame pair, 64 pixels).  Rows are ordered so that the two frames of a pixel
 // are accumulator tiles j and j + 2 of the SAME lane: the pair max needs no exchange at all.
 #include "af_common.h"
+#include <stdlib.h>
 
 namespace af {
 
@@ -393,11 +394,19 @@ int conv111_run(const af_conv_desc* d, const void* in, const void* w_packed, con
     if (d2) return AF_C111(1, 1, false, false);
     if (d->tpool) return residual ? AF_C111(1, 0, true, true) : AF_C111(1, 0, true, false);
     if (d->cin == 64) return residual ? AF_C111(1, 0, false, true) : AF_C111(1, 0, false, false);
-    // (64-channel wave columns for K = 256 - 128-byte row segments instead of 64 - were tried in round 4: 128 weight registers next to
-    //  three residual sets spill 11 registers at two waves per SIMD, and a scratch reload's vmcnt(0) is poison in this loop)
-    if (d->cin == 256)     // 32-channel wave columns: the weights of 64 channels x 256 would not fit the registers
+    // K = 256 (s4 `c`).  Round 4, late: 64-channel wave columns - 128-byte row segments for the residual rows and the output instead of
+    // 64 - with a TWO-slot ring.  128 weight registers next to the three residual sets of the 4-slot ring spilled 11 registers (and a
+    // scratch reload's vmcnt(0) is poison in this loop), which is why rounds 2-4 ran this layer on 32-channel columns; with ONE residual
+    // set (one tile ahead) it is 242 registers, and one tile of look-ahead on full lines beats three tiles of it on half lines:
+    // 58.6 -> 49.9 us (tools/exp_c111_wc64.py, interleaved on one box).  AF_C111_WC64=0: the 32-channel form, for A/B runs.
+    if (d->cin == 256) {
+        const char* ewc = getenv("AF_C111_WC64");
+        if (!(ewc && atoi(ewc) == 0))
+            return residual ? (bf ? launch111<AF_BF16, 4, 0, false, true, 64, 64, 2>(a, blocks, stream) : launch111<AF_F16, 4, 0, false, true, 64, 64, 2>(a, blocks, stream))
+                            : (bf ? launch111<AF_BF16, 4, 0, false, false, 64, 64, 2>(a, blocks, stream) : launch111<AF_F16, 4, 0, false, false, 64, 64, 2>(a, blocks, stream));
         return residual ? (bf ? launch111<AF_BF16, 4, 0, false, true, 32, 64, 4>(a, blocks, stream) : launch111<AF_F16, 4, 0, false, true, 32, 64, 4>(a, blocks, stream))
                         : (bf ? launch111<AF_BF16, 4, 0, false, false, 32, 64, 4>(a, blocks, stream) : launch111<AF_F16, 4, 0, false, false, 32, 64, 4>(a, blocks, stream));
+    }
     // K = 128: tiles of 64 positions as well (16-KB stages), three tiles ahead
     return residual ? (bf ? launch111<AF_BF16, 2, 0, false, true, 64, 64, 4>(a, blocks, stream) : launch111<AF_F16, 2, 0, false, true, 64, 64, 4>(a, blocks, stream))
                     : (bf ? launch111<AF_BF16, 2, 0, false, false, 64, 64, 4>(a, blocks, stream) : launch111<AF_F16, 2, 0, false, false, 64, 64, 4>(a, blocks, stream));
