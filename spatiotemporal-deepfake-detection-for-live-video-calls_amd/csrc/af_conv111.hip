@@ -399,6 +399,7 @@ int conv111_run(const af_conv_desc* d, const void* in, const void* w_packed, con
     // scratch reload's vmcnt(0) is poison in this loop), which is why rounds 2-4 ran this layer on 32-channel columns; with ONE residual
     // set (one tile ahead) it is 242 registers, and one tile of look-ahead on full lines beats three tiles of it on half lines:
     // 58.6 -> 49.9 us (tools/exp_c111_wc64.py, interleaved on one box).  AF_C111_WC64=0: the 32-channel form, for A/B runs.
+    // (A three-slot ring with the BN parameters moved to LDS - 256 registers, no spills - measured the same as two slots: 49.0 us.)
     if (d->cin == 256) {
         const char* ewc = getenv("AF_C111_WC64");
         if (!(ewc && atoi(ewc) == 0))
