@@ -38,15 +38,16 @@ def main():
     os.makedirs("profiles", exist_ok=True)
     shutil.copy(os.path.join(src, "bench.json"), "profiles/%s_bench.json" % name)
     shutil.copy(os.path.join(src, "layers.json"), "profiles/%s_layers.json" % name)
-    stats = glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv"))
+    newest = lambda pattern: sorted(glob.glob(pattern), key=os.path.getmtime, reverse=True)    # a re-used tag keeps the earlier run's files: take the latest
+    stats = newest(os.path.join(src, "trace", "*", "*kernel_stats.csv"))
     if stats:
         shutil.copy(stats[0], "profiles/%s_kernel_stats.csv" % name)
-    f = glob.glob(os.path.join(src, "pmc_fetch", "*", "*counter_collection.csv"))
-    w = glob.glob(os.path.join(src, "pmc_write", "*", "*counter_collection.csv"))
+    f = newest(os.path.join(src, "pmc_fetch", "*", "*counter_collection.csv"))
+    w = newest(os.path.join(src, "pmc_write", "*", "*counter_collection.csv"))
     if f and w:
         fetch, write = per_kernel(f[0], "FETCH_SIZE"), per_kernel(w[0], "WRITE_SIZE")
         out = {}
-        m = glob.glob(os.path.join(src, "pmc_mfma", "*", "*counter_collection.csv"))
+        m = newest(os.path.join(src, "pmc_mfma", "*", "*counter_collection.csv"))
         mfma = per_kernel(m[0], "SQ_VALU_MFMA_BUSY_CYCLES") if m else {}
         gui = per_kernel(m[0], "GRBM_GUI_ACTIVE") if m else {}
         for k in fetch:
