@@ -31,7 +31,7 @@ namespace af {
 #define AF_STAMP_DECL unsigned long long stamp_v[8] = {0, 0, 0, 0, 0, 0, 0, 0}
 #define AF_DBG(bit) (a.dbg & (bit))
 #define AF_STAMP(slot) stamp_v[slot] = (slot) >= 6 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime()
-#define AF_STAMP_FLUSH do { if (a.stamps && lane < 8) a.stamps[((long long)blockIdx.x * 8 + wave) * 8 + lane] = \
+#define AF_STAMP_FLUSH do { if (a.stamps && lane < 8) a.stamps[((long long)bid * 8 + wave) * 8 + lane] = \
     lane == 0 ? stamp_v[0] : lane == 1 ? stamp_v[1] : lane == 2 ? stamp_v[2] : lane == 3 ? stamp_v[3] : lane == 4 ? stamp_v[4] : lane == 5 ? stamp_v[5] : lane == 6 ? stamp_v[6] : stamp_v[7]; } while (0)
 #else
 #define AF_STAMP_DECL do {} while (0)
@@ -66,6 +66,9 @@ struct ConvArgs {
     // split-K (small batches: a long-K layer with a handful of tiles): workgroup (tile, blockIdx.y) multiplies K-steps
     // [y * S / ksplit, (y + 1) * S / ksplit) and leaves raw fp32 partial sums in ws[y][M][Cout]; splitk_finish_kernel adds them
     int ksplit;
+    // row index -> (n, to, ho, wo): division by the three output extents as multiply-high + shift (exact for 32-bit numerators;
+    // Granlund-Montgomery: l = ceil(log2 d), m = floor(2^32 (2^l - d) / d) + 1, q = (t + ((n - t) >> 1)) >> (l - 1), t = mulhi(m, n))
+    unsigned div_w_m, div_w_l, div_h_m, div_h_l, div_t_m, div_t_l;
     float* ws;
     long long ws_bytes;  // caller's workspace (ws == nullptr or too small: no split)
 #ifdef AF_STAMPS
@@ -81,8 +84,9 @@ struct ConvArgs {
 // DUAL compiles in the second K segment (projection shortcut accumulated into the same tile).
 // BMR < BM: the tile covers BMR output positions (frame-aligned tile counts: 224 rows = 224 tiles for the 50 176 positions
 // of a 16-clip s4 / s5 tensor instead of 196 on 256 CUs); its LDS image keeps BM rows, rows BMR.. are fetched as zeros.
+// One tile (bid of nb) of the layer.
 template <int DT, int BN, int BM, int WN, int WM, int KS, int NSTAGE, int MINW, bool DUAL, bool SPLITK, int BMR>
-__global__ __launch_bounds__(WN * WM * KS * 64, MINW) void conv_igemm_kernel(const ConvArgs a) {
+__device__ __forceinline__ void conv_igemm_tile(const ConvArgs& a, const int bid, const int nb) {
     typedef Elem<DT> E;
     constexpr int EPC = E::EPC;            // elements per 16-byte chunk
     constexpr int ES = 16 / EPC;           // bytes per element
@@ -103,7 +107,6 @@ __global__ __launch_bounds__(WN * WM * KS * 64, MINW) void conv_igemm_kernel(con
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 
     // ---- workgroup -> tile, XCD-contiguous (bijective remap; placement is a speed matter only)
-    const int bid = blockIdx.x, nb = gridDim.x;
     const int xcd = bid & 7, q = nb >> 3, r = nb & 7;
     const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     const int tile_n = swz % a.tiles_n;
@@ -125,12 +128,20 @@ __global__ __launch_bounds__(WN * WM * KS * 64, MINW) void conv_igemm_kernel(con
         // tile row -> output position.  With the temporal pool fused, rows are ordered (n, to/2, ho, wo, to%2):
         // the two frames a pool window spans are ADJACENT rows of the tile (the epilogue takes their max)
         // (spatial 2x2 pool fused: rows are ordered (n, to, ho/2, wo/2, dy, dx) - a window = 4 adjacent rows)
-        const long long mq = a.tpool == 2 ? (m >> 2) : a.tpool ? (m >> 1) : m;
-        const int wdiv = a.tpool == 2 ? (a.Wo >> 1) : a.Wo, hdiv = a.tpool == 2 ? (a.Ho >> 1) : a.Ho;
-        int wo = (int)(mq % wdiv); long long t1 = mq / wdiv;
-        int ho = (int)(t1 % hdiv); long long t2 = t1 / hdiv;
-        const int tdiv = a.tpool == 1 ? (a.To >> 1) : a.To;
-        int to = (int)(t2 % tdiv); long long n = t2 / tdiv;
+        // (round 4, late: 32-bit multiply-high divisions.  The three 64-bit div / mod pairs per row - five rows per thread - were the bulk
+        //  of ~11 k cycles every workgroup spent in front of its first DMA: in-kernel stamps put a tile of s3's projection block at
+        //  25.7 k cycles and the 7-tile launch at 115 us = 37 k per tile; persistent workgroups alone changed nothing, so it was not the
+        //  dispatch.  M < 2^31 is checked on the host.)
+        const unsigned mq = (unsigned)(a.tpool == 2 ? (m >> 2) : a.tpool ? (m >> 1) : m);
+        const unsigned wdiv = (unsigned)(a.tpool == 2 ? (a.Wo >> 1) : a.Wo), hdiv = (unsigned)(a.tpool == 2 ? (a.Ho >> 1) : a.Ho);
+        auto fdiv = [](unsigned x, unsigned mm, unsigned l) { const unsigned t = __umulhi(mm, x); return l == 0 ? x : (t + ((x - t) >> 1)) >> (l - 1); };
+        const unsigned t1 = fdiv(mq, a.div_w_m, a.div_w_l);
+        int wo = (int)(mq - t1 * wdiv);
+        const unsigned t2 = fdiv(t1, a.div_h_m, a.div_h_l);
+        int ho = (int)(t1 - t2 * hdiv);
+        const unsigned tdiv = (unsigned)(a.tpool == 1 ? (a.To >> 1) : a.To);
+        const unsigned nq = fdiv(t2, a.div_t_m, a.div_t_l);
+        int to = (int)(t2 - nq * tdiv); const long long n = nq;
         if (a.tpool == 1) to = 2 * to + (int)(m & 1);
         if (a.tpool == 2) { ho = 2 * ho + (int)((m >> 1) & 1); wo = 2 * wo + (int)(m & 1); }
         const int ti0 = to * a.st - a.pt, hi0 = ho * a.sh - a.ph, wi0 = wo * a.sw - a.pw;
@@ -703,6 +714,17 @@ __global__ __launch_bounds__(WN * WM * KS * 64, MINW) void conv_igemm_kernel(con
     AF_STAMP_FLUSH;
 }
 
+// (Round 4, late: PERSISTENT workgroups - a workgroup walking tiles blockIdx.x, blockIdx.x + gridDim.x, ... - were built on this body and
+// dropped.  Inlined into a tile loop hipcc keeps the body's tile-invariant values alive across it: 106 scalar registers everywhere,
+// 5-41 spilled vector registers in three tile shapes; as a noinline call the tile's arguments arrive in vector registers and the
+// re-read argument block lands in scratch.  On the two shapes that compile clean (256 x 224 / 256 on 4 x 2 waves, 128 x 256) the layers
+// ran 1-4 % SLOWER than one workgroup per tile: the 5 us per round they were meant to remove were not the dispatch but the 64-bit
+// divisions of `row_offsets`, see there.)
+template <int DT, int BN, int BM, int WN, int WM, int KS, int NSTAGE, int MINW, bool DUAL, bool SPLITK, int BMR>
+__global__ __launch_bounds__(WN * WM * KS * 64, MINW) void conv_igemm_kernel(const ConvArgs a) {
+    conv_igemm_tile<DT, BN, BM, WN, WM, KS, NSTAGE, MINW, DUAL, SPLITK, BMR>(a, blockIdx.x, gridDim.x);
+}
+
 template <int DT, int BN, int BM, int WN, int WM, int KS, int MINW, bool DUAL, int NSTAGE = 3, bool SPLITK = false, int BMR = BM>
 static int launch(const ConvArgs& a, hipStream_t stream) {
     const long long tiles_m = (a.M + BMR - 1) / BMR;
@@ -960,6 +982,16 @@ static int conv_common(const af_conv_desc* d, const void* in, const void* w_pack
     AF_REQUIRE(a.tpool != 2 || (ho % 2 == 0 && wo % 2 == 0 && !residual && !d2),
                "conv: the fused 2x2 pool needs even output height / width (%d x %d), no residual and no second segment", ho, wo);
     a.M = (long long)d->n * to * ho * wo;
+    AF_REQUIRE(a.M < (1LL << 31), "conv: %lld output positions (the row index is 32-bit)", a.M);
+    {
+        auto magic = [](unsigned dv, unsigned& mm, unsigned& l) {
+            l = 0; while ((1ull << l) < dv) ++l;
+            mm = (unsigned)(((1ull << 32) * ((1ull << l) - dv)) / dv + 1);
+        };
+        magic((unsigned)(a.tpool == 2 ? (wo >> 1) : wo), a.div_w_m, a.div_w_l);
+        magic((unsigned)(a.tpool == 2 ? (ho >> 1) : ho), a.div_h_m, a.div_h_l);
+        magic((unsigned)(a.tpool == 1 ? (to >> 1) : to), a.div_t_m, a.div_t_l);
+    }
     a.in2 = nullptr; a.w2 = (const char*)w_packed; a.T2 = a.H2 = a.W2 = 1; a.Cin2 = a.Cin2P = bk; a.st2 = a.sh2 = a.sw2 = 1; a.kpt2 = 0;
     if (d2) {
         AF_REQUIRE(in2 && w2_packed && aligned16(in2) && aligned16(w2_packed), "conv: second segment needs in2 / w2");
