@@ -105,6 +105,8 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& a, const int bid
 
     extern __shared__ uint4 smem[];
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    AF_STAMP_DECL;
+    AF_STAMP(4);                                       // (diagnostic build: entry; stamp 0 sits behind the address set-up)
 
     // ---- workgroup -> tile, XCD-contiguous (bijective remap; placement is a speed matter only)
     const int xcd = bid & 7, q = nb >> 3, r = nb & 7;
@@ -147,15 +149,13 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& a, const int bid
         const int ti0 = to * a.st - a.pt, hi0 = ho * a.sh - a.ph, wi0 = wo * a.sw - a.pw;
         off1 = ((((n * a.T + ti0) * a.H + hi0) * a.W + wi0) * a.Cin) * ES;
         off2 = DUAL ? ((((n * a.T2 + to * a.st2) * a.H2 + ho * a.sh2) * a.W2 + wo * a.sw2) * a.Cin2) * ES : 0;
-        mask = 1u << 31;
-        int tap = 0;
-        for (int dt = 0; dt < a.kt; ++dt)
-            for (int dh = 0; dh < a.kh; ++dh)
-                for (int dw = 0; dw < a.kw; ++dw, ++tap) {
-                    bool ok = (unsigned)(ti0 + dt) < (unsigned)a.T && (unsigned)(hi0 + dh) < (unsigned)a.H &&
-                              (unsigned)(wi0 + dw) < (unsigned)a.W;
-                    mask |= (ok ? 1u : 0u) << tap;
-                }
+        // bit (dt * kh + dh) * kw + dw: tap in bounds - built per axis (kt + kh + kw steps, not kt * kh * kw: this runs five times per
+        // thread in front of a workgroup's first DMA)
+        unsigned mw = 0, mhw = 0, mthw = 0;
+        for (int dw = 0; dw < a.kw; ++dw) mw |= ((unsigned)(wi0 + dw) < (unsigned)a.W ? 1u : 0u) << dw;
+        for (int dh = 0; dh < a.kh; ++dh) mhw |= ((unsigned)(hi0 + dh) < (unsigned)a.H ? mw : 0u) << (dh * a.kw);
+        for (int dt = 0; dt < a.kt; ++dt) mthw |= ((unsigned)(ti0 + dt) < (unsigned)a.T ? mhw : 0u) << (dt * a.kh * a.kw);
+        mask = (1u << 31) | mthw;
     };
     long long org1, org2; unsigned org_mask;
     row_offsets(m0, org1, org2, org_mask);               // uniform: tile row 0 always exists
@@ -234,7 +234,6 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& a, const int bid
     const int s_lo = SPLITK ? (int)((long long)blockIdx.y * S_all / a.ksplit) : 0;
     const int S = (SPLITK ? (int)((long long)(blockIdx.y + 1) * S_all / a.ksplit) : S_all) - s_lo;
     if (SPLITK) for (int i = 0; i < s_lo; ++i) advance();
-    AF_STAMP_DECL;
     AF_STAMP(0); AF_STAMP(6);
     issue_stage(0);
     if (S > 1 && !(LEAN && a.ring == 2)) issue_stage(1);

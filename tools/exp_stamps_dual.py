@@ -23,8 +23,9 @@ for name, d, d2, wgs, ksteps in CASES:
         torch.cuda.synchronize()
         s = buf.cpu().view(wgs, 8, 8).double()
         pro, loop, epi, tot = s[:, :, 1] - s[:, :, 0], s[:, :, 2] - s[:, :, 1], s[:, :, 3] - s[:, :, 2], s[:, :, 3] - s[:, :, 0]
+        setup = s[:, :, 0] - s[:, :, 4]
         clk = tot / (s[:, :, 7] - s[:, :, 6]) * 0.1
         med = lambda t, w: t[:, w].median().item()
         span = (s[:, :, 3].max() - s[:, :, 0].min()).item()
-        print("%-22s dbg=%d launch %6.1f us | cycles wave0: prologue %6.0f loop %7.0f (%5.0f / K-step) epilogue %6.0f total %7.0f | wave4 loop %7.0f | clock %.2f GHz | all workgroups, first start -> last end %.0f"
-              % (name, dbg, us, med(pro, 0), med(loop, 0), med(loop, 0) / ksteps, med(epi, 0), med(tot, 0), med(loop, 4), clk.median().item(), span), flush=True)
+        print("%-22s dbg=%d launch %6.1f us | cycles wave0: set-up %6.0f prologue %6.0f loop %7.0f (%5.0f / K-step) epilogue %6.0f total %7.0f | wave4 loop %7.0f | clock %.2f GHz | all workgroups, first start -> last end %.0f"
+              % (name, dbg, us, med(setup, 0), med(pro, 0), med(loop, 0), med(loop, 0) / ksteps, med(epi, 0), med(tot, 0), med(loop, 4), clk.median().item(), span), flush=True)
