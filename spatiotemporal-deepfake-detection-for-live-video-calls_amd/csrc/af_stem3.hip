@@ -124,7 +124,11 @@ __global__ __launch_bounds__(512, 2) void stem3_pool_kernel(const Stem3Args a) {
                 const int b = grp * GB + k;
                 if (b < NBLK) {
                     dst[k][0] = *reinterpret_cast<const uint4*>(rb0 + (unsigned)fo_tab[b]);
+#ifdef AF_STEM_NO_ROW1_LOADS                               // timing-only ablation (diagnostic builds): what do the second row's loads cost?
+                    dst[k][1] = dst[k][0];
+#else
                     dst[k][1] = *reinterpret_cast<const uint4*>(rb1 + (unsigned)fo_tab[b]);
+#endif
                 }
             }
         };
