@@ -157,8 +157,11 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& a, const int bid
         for (int dt = 0; dt < a.kt; ++dt) mthw |= ((unsigned)(ti0 + dt) < (unsigned)a.T ? mhw : 0u) << (dt * a.kh * a.kw);
         mask = (1u << 31) | mthw;
     };
+    // (a 1x1x1 / stride-1 / unpadded / unpooled one-input layer - most `a` and `c` convs - reads row m at m * Cin: no (n, t, h, w) at all)
+    const bool flat_rows = !DUAL && taps == 1 && a.tpool == 0 && a.st == 1 && a.sh == 1 && a.sw == 1 && a.pt == 0 && a.ph == 0 && a.pw == 0;
     long long org1, org2; unsigned org_mask;
-    row_offsets(m0, org1, org2, org_mask);               // uniform: tile row 0 always exists
+    if (flat_rows) { org1 = m0 * a.Cin * ES; org2 = 0; }
+    else row_offsets(m0, org1, org2, org_mask);          // uniform: tile row 0 always exists
     const i32x4 xdesc = make_desc(a.in + org1);
     const i32x4 x2desc = make_desc((DUAL ? a.in2 : a.in) + org2);
     unsigned xoff[RX], x2off[RX];
@@ -168,10 +171,15 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvArgs& a, const int bid
         const long long m = m0 + lrow + GR * i;
         xmask[i] = 0; xoff[i] = kOutOfRange; x2off[i] = kOutOfRange;
         if (m < a.M && (BMR == BM || lrow + GR * i < BMR)) {
-            long long o1, o2;
-            row_offsets(m, o1, o2, xmask[i]);
-            xoff[i] = (unsigned)(o1 - org1) + chunk * 16;       // < 2 GiB (host-checked span)
-            x2off[i] = (unsigned)(o2 - org2) + chunk * 16;
+            if (flat_rows) {
+                xmask[i] = (1u << 31) | 1u;
+                xoff[i] = (unsigned)((lrow + GR * i) * a.Cin * ES) + chunk * 16;
+            } else {
+                long long o1, o2;
+                row_offsets(m, o1, o2, xmask[i]);
+                xoff[i] = (unsigned)(o1 - org1) + chunk * 16;   // < 2 GiB (host-checked span)
+                x2off[i] = (unsigned)(o2 - org2) + chunk * 16;
+            }
         }
     }
     const long long Kw = (long long)taps * a.CinP;     // weight row length (elements, zero-padded per tap)
