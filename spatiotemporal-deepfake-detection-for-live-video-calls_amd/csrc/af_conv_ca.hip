@@ -37,7 +37,8 @@ struct CAArgs {
     int P, chunks, tiles;
 #ifdef AF_STAMPS
     int dbg;             // diagnostic build only: timing-only ablations (AF_CA_DBG; outputs are then garbage): 1 no c-weight loads after
-                         // the first stage, 2 no b-fragment loads after the first tile, 4 no `a` output stores, 8 no trunk stores
+                         // the first stage, 2 no b-fragment loads after the first tile, 4 no `a` output stores, 8 no trunk stores,
+                         // 16 the b / x0 bytes as whole 128-byte rows (8 rows x 8 chunks per instruction; the operands are then garbage)
 #endif
 };
 #ifdef AF_STAMPS
@@ -156,8 +157,13 @@ __global__ __launch_bounds__(512, 2) void conv_ca_kernel(const CAArgs a) {
             const int r = wm * 32 + j * 16 + frow, t = r / P, p = r - t * P;
             const int pc = hw0 + p < a.HW ? p : 0;                    // a pixel beyond the frame: any valid row (its outputs are dropped)
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
+            for (int kk = 0; kk < 2; ++kk) {
+                if (CA_DBG(16)) {                                    // timing only: the same bytes as whole 128-byte rows (8 rows x 8 chunks per instruction)
+                    const int r8 = wm * 32 + (2 * j + kk) * 8 + (lane >> 3), t8 = r8 / P, p8 = r8 - t8 * P;
+                    dst[j][kk] = gload16_uncounted(bb + (((long long)t8 * a.HW + (hw0 + p8 < a.HW ? p8 : 0)) * 64 + (lane & 7) * 8) * 2);
+                } else
                 dst[j][kk] = gload16_uncounted(bb + (((long long)t * a.HW + pc) * 64 + kk * 32 + fg * 8) * 2);
+            }
         }
     };
 

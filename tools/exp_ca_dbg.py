@@ -12,7 +12,7 @@ x = synth.normalize_like_callers(synth.synthetic_clips_u8(16, seed=2026, kind="u
 with torch.inference_mode():
     clf(x)
     eng = clf.network._engines[("bf16", 16, (32, 224, 224))]
-    for dbg in (0, 1, 2, 4, 8, 3, 12, 15, 0):
+    for dbg in (0, 1, 2, 4, 8, 16, 3, 12, 15, 0):
         os.environ["AF_CA_DBG"] = str(dbg)
         best = {}
         for rep in range(5):
