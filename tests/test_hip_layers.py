@@ -630,6 +630,42 @@ def test_fused_c_a_vs_oracle(name, ctrunk, dims, dtype):
     assert ea <= 1.5 * tol * (want_a.abs().max().item() + 1e-9), "%s[%s] a err %.3e" % (name, dtype, ea)   # a trunk value on a rounding boundary may round the other way
 
 
+@pytest.mark.parametrize("env", [("AF_CA_CWL", "0"), ("AF_C111_WC64", "0")])
+def test_ab_forms_behind_environment_switches_stay_correct(env, monkeypatch):
+    """The forms round 4 replaced stay in the library for A/B runs (conv_ca with per-wave fragment loads of the c weights: AF_CA_CWL=0;
+    the K = 256 stream on 32-channel wave columns: AF_C111_WC64=0): the same layers, bit-identical results to the shipped forms
+    (the arithmetic and its order do not change, only how operands and results travel)."""
+    dtype = "bf16"
+    tdt = hh.TORCH_DT[dtype]
+    if env[0] == "AF_CA_CWL":
+        seed = 777
+        lay = [("c.weight", (256, 64, 1, 1, 1), "float32"), ("a.weight", (64, 256, 3, 1, 1), "float32")]
+        for p_, ch in (("c_bn", 256), ("a_bn", 64)):
+            lay += [(p_ + s_, (ch,), "float32") for s_ in (".weight", ".bias", ".running_mean", ".running_var")]
+        sd = synth.fill_layout(lay, seed)
+        b = synth.synthetic_tensor((2, 64, 32, 64, 66), seed).to(tdt).float()
+        res = synth.synthetic_tensor((2, 256, 32, 64, 66), seed + 1).to(tdt).float()
+        run = lambda: hh.conv_ca(hh.to_ndhwc(b, dtype), sd["c.weight"], hh.fold_bn(sd, "c_bn"), hh.to_ndhwc(res, dtype), sd["a.weight"],
+                                 hh.fold_bn(sd, "a_bn"), dtype)
+        ref = [t_.clone() for t_ in run()]
+        monkeypatch.setenv(*env)
+        got = run()
+        assert all(torch.equal(g, r) for g, r in zip(got, ref))
+    else:
+        seed = 778
+        lay = [("w.weight", (1024, 256, 1, 1, 1), "float32"), ("bn.weight", (1024,), "float32"), ("bn.bias", (1024,), "float32"),
+               ("bn.running_mean", (1024,), "float32"), ("bn.running_var", (1024,), "float32")]
+        sd = synth.fill_layout(lay, seed)
+        x = synth.synthetic_tensor((1, 256, 4, 91, 93), seed).to(tdt).float()
+        res = synth.synthetic_tensor((1, 1024, 4, 91, 93), seed + 1).to(tdt).float()
+        run = lambda: hh.conv_bn_act(hh.to_ndhwc(x, dtype), sd["w.weight"], *hh.fold_bn(sd, "bn"), (1, 1, 1), (0, 0, 0), True, dtype,
+                                     residual=hh.to_ndhwc(res, dtype))
+        ref = run().clone()
+        assert hh.conv_bn_act.last_variant == 10
+        monkeypatch.setenv(*env)
+        assert torch.equal(run(), ref)
+
+
 @pytest.mark.parametrize("dtype", ["f16", "bf16"])
 @pytest.mark.parametrize("x_sub", [2, 1])
 @pytest.mark.parametrize("name,ctrunk,dims", [
